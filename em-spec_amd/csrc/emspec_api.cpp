@@ -1,0 +1,440 @@
+// emspec_api.cpp — the C ABI of libemspec (include/emspec.h): engine, plan
+// cache, streaming state, host<->device staging.  Compiled with hipcc.
+//
+// No reference FFI exists to mirror (reference source is private,
+// /root/reference/README.md:73); the contract is SURVEY.md §8(b).
+// There is deliberately NO CPU path here: without a gfx950 device
+// emspec_create fails.
+#include "../../include/emspec.h"
+#include "emspec_launch.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace emspec;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct Plan {
+    int n = 0;
+    float2* d_tw = nullptr;
+    float* d_ebin = nullptr;
+    std::vector<float> h_tw, h_ebin;
+};
+
+}  // namespace
+
+struct emspec_engine {
+    emspec_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string arch;
+    mutable std::string err;
+    std::map<int, Plan> plans;
+    uint8_t* d_lut = nullptr;
+    // batch workspace (generic path histogram; host-API staging)
+    float* d_hist = nullptr;
+    size_t hist_bytes = 0;
+    char* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // streaming state
+    int st_n = 0, st_hop = 0, st_reassign = -1, st_D = 0;
+    int64_t st_fed = 0;       // frames fed so far
+    int64_t st_emitted = 0;   // columns emitted so far (flush included)
+    float* d_ring = nullptr;  // [W+1][rows]; slot W stays zero (the empty column)
+    size_t ring_bytes = 0;
+    float* d_frame = nullptr;
+    size_t frame_bytes = 0;
+    float* d_coldb = nullptr;
+    uint8_t* d_colrgba = nullptr;
+};
+
+namespace {
+
+int fail(const emspec_engine* e, int code, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                          \
+    do {                                                                                         \
+        hipError_t _r = (call);                                                                  \
+        if (_r != hipSuccess)                                                                    \
+            return fail((e), _r == hipErrorOutOfMemory ? EMSPEC_ERR_OUT_OF_MEMORY : EMSPEC_ERR_HIP, \
+                        std::string(#call) + ": " + hipGetErrorString(_r));                      \
+    } while (0)
+
+void default_lut(uint8_t* lut) {
+    // 5-stop gradient measured from the reference's settings screenshot
+    // (assets/settings.png): 0/25/50/75/100 %.
+    static const int stops[5][3] = {{0, 0, 0}, {80, 0, 80}, {200, 50, 50}, {255, 150, 0}, {255, 255, 200}};
+    for (int i = 0; i < 256; ++i) {
+        const int pos = 4 * i;
+        const int seg = pos >= 3 * 255 ? 3 : pos / 255;
+        const int w1 = pos - seg * 255, w0 = 255 - w1;
+        for (int c = 0; c < 3; ++c) lut[4 * i + c] = (uint8_t)((stops[seg][c] * w0 + stops[seg + 1][c] * w1 + 127) / 255);
+        lut[4 * i + 3] = 255;
+    }
+}
+
+int latency(int n, int hop, int reassign) { return reassign ? (n + 2 * hop - 1) / (2 * hop) : 0; }
+
+int check_shape(const emspec_engine* e, int n, int hop) {
+    if (!supported_fft(n)) return fail(e, EMSPEC_ERR_INVALID_ARG, "fft size must be a power of two in [256,16384]");
+    if (hop < 1 || hop > n) return fail(e, EMSPEC_ERR_INVALID_ARG, "hop must be in [1, fft size]");
+    return EMSPEC_OK;
+}
+
+// DESIGN.md §3 "Tables": evaluated in double, rounded once to float.
+int get_plan(emspec_engine* e, int n, Plan** out) {
+    auto it = e->plans.find(n);
+    if (it != e->plans.end()) { *out = &it->second; return EMSPEC_OK; }
+    Plan p;
+    p.n = n;
+    p.h_tw.resize(n);
+    const double pi = 3.14159265358979323846;
+    for (int q = 0; q < n / 2; ++q) {
+        const double a = 2.0 * pi * (double)q / (double)n;
+        p.h_tw[2 * q] = (float)std::cos(a);
+        p.h_tw[2 * q + 1] = (float)(-std::sin(a));
+    }
+    p.h_tw[2 * (n / 4)] = 0.0f;       // quarter turn is exact: (0,-1)
+    p.h_tw[2 * (n / 4) + 1] = -1.0f;
+    const int R = e->cfg.rows;
+    p.h_ebin.resize(R + 1);
+    const double ratio = (double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz;
+    for (int r = 0; r <= R; ++r)
+        p.h_ebin[r] = (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n /
+                              (double)e->cfg.sample_rate);
+    for (int r = 0; r < R; ++r)
+        if (!(p.h_ebin[r] < p.h_ebin[r + 1])) return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges are not strictly increasing in float32 (too many rows for this range)");
+    HIPCHK(e, hipMalloc(&p.d_tw, sizeof(float) * n));
+    HIPCHK(e, hipMalloc(&p.d_ebin, sizeof(float) * (R + 1)));
+    HIPCHK(e, hipMemcpy(p.d_tw, p.h_tw.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(p.d_ebin, p.h_ebin.data(), sizeof(float) * (R + 1), hipMemcpyHostToDevice));
+    auto ins = e->plans.emplace(n, std::move(p));
+    *out = &ins.first->second;
+    return EMSPEC_OK;
+}
+
+PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
+    PlanDev d;
+    d.tw = p.d_tw;
+    d.ebin = p.d_ebin;
+    d.rows = e->cfg.rows;
+    d.D = latency(p.n, hop, reassign);
+    d.reassign = reassign ? 1 : 0;
+    d.hop = hop;
+    d.tscale = (float)((double)p.n / 2.0 / (double)hop);
+    const double pk = (double)p.n / 4.0;   // |X_h| of a full-scale sine
+    d.pfloor_abs = (float)((double)e->cfg.power_floor * pk * pk);
+    return d;
+}
+
+DbMap db_map(const emspec_engine* e, int n) {
+    DbMap m;
+    const double nn = (double)n;
+    m.scale = (float)(32.0 / (3.0 * nn * nn) * (double)e->cfg.gain * (double)e->cfg.gain);
+    m.lo = e->cfg.db_top - e->cfg.db_range;
+    m.inv_range = (float)(1.0 / (double)e->cfg.db_range);
+    m.gate = e->cfg.gate_db;
+    return m;
+}
+
+int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
+    if (*have >= want) return EMSPEC_OK;
+    if (*ptr) { HIPCHK(e, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIPCHK(e, hipMalloc(ptr, want));
+    *have = want;
+    return EMSPEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emspec_default_config(emspec_config* c) {
+    if (!c) return EMSPEC_ERR_INVALID_ARG;
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = EMSPEC_ABI_VERSION;
+    c->device = 0;
+    c->rows = 1024;
+    c->sample_rate = 48000.0f;
+    c->fmin_hz = 20.0f;
+    c->fmax_hz = 24000.0f;
+    c->gain = 1.0f;
+    c->db_top = 0.0f;
+    c->db_range = 80.0f;
+    c->gate_db = -80.0f;
+    c->power_floor = 1e-14f;
+    return EMSPEC_OK;
+}
+
+int emspec_create(const emspec_config* cfg, emspec_engine** out) {
+    if (!cfg || !out) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != EMSPEC_ABI_VERSION) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "abi_version mismatch");
+    if (cfg->rows < 64 || cfg->rows > 4096 || cfg->rows % 4) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "rows must be a multiple of 4 in [64,4096]");
+    if (!(cfg->sample_rate > 0) || !(cfg->fmin_hz > 0) || !(cfg->fmax_hz > cfg->fmin_hz) || !(cfg->db_range > 0) ||
+        !(cfg->gain > 0) || !(cfg->power_floor >= 0))
+        return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "bad sample_rate/fmin/fmax/db_range/gain/power_floor");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, EMSPEC_ERR_NO_DEVICE, "no HIP device available (libemspec has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, EMSPEC_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, EMSPEC_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, EMSPEC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    emspec_engine* e = new (std::nothrow) emspec_engine();
+    if (!e) return fail(nullptr, EMSPEC_ERR_OUT_OF_MEMORY, "out of host memory");
+    e->cfg = *cfg;
+    e->device = cfg->device;
+    e->arch = prop.gcnArchName;
+    int rc = EMSPEC_OK;
+    do {
+        if (hipSetDevice(e->device) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipSetDevice failed"); break; }
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipStreamCreate failed"); break; }
+        if (hipMalloc(&e->d_lut, 1024) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_OUT_OF_MEMORY, "hipMalloc(lut) failed"); break; }
+        uint8_t lut[1024];
+        default_lut(lut);
+        if (hipMemcpy(e->d_lut, lut, 1024, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "lut upload failed"); break; }
+    } while (0);
+    if (rc != EMSPEC_OK) { emspec_destroy(e); return rc; }
+    *out = e;
+    return EMSPEC_OK;
+}
+
+void emspec_destroy(emspec_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->plans) { (void)hipFree(kv.second.d_tw); (void)hipFree(kv.second.d_ebin); }
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
+    (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* emspec_last_error(const emspec_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
+
+int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba) {
+    if (!e || !rgba) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(e->d_lut, rgba, 1024, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
+int64_t emspec_num_columns(int64_t L, int32_t n, int32_t hop) {
+    if (n <= 0 || hop <= 0 || L < n) return 0;
+    return (L - n) / hop + 1;
+}
+
+int32_t emspec_latency_columns(int32_t n, int32_t hop, int32_t reassign) {
+    if (n <= 0 || hop <= 0) return 0;
+    return latency(n, hop, reassign);
+}
+
+int emspec_get_tables(emspec_engine* e, int32_t n, float* edges, float* tw) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    int rc = check_shape(e, n, 1);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    // read back what the kernels actually see
+    if (edges) HIPCHK(e, hipMemcpy(edges, p->d_ebin, sizeof(float) * (e->cfg.rows + 1), hipMemcpyDeviceToHost));
+    if (tw) HIPCHK(e, hipMemcpy(tw, p->d_tw, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return EMSPEC_OK;
+}
+
+int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                        int32_t reassign, float* db, uint8_t* rgba, uint8_t* index, void* hip_stream) {
+    if (!e || !pcm) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    const DbMap m = db_map(e, n);
+    const int64_t C = emspec_num_columns(L, n, hop);
+    if (!db && !rgba && !index) return EMSPEC_OK;
+    if (fused_supported(n, hop, e->cfg.rows, reassign)) {
+        HIPCHK(e, launch_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
+        return EMSPEC_OK;
+    }
+    // generic path: global-atomic histogram, then dB/colour
+    const size_t cells = (size_t)S * C * e->cfg.rows;
+    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, cells * sizeof(float)))) return rc;
+    HIPCHK(e, hipMemsetAsync(e->d_hist, 0, cells * sizeof(float), st));
+    FrameSinks sk;
+    sk.hist = e->d_hist;
+    sk.hist_slots = C;
+    sk.total_cols = C;
+    HIPCHK(e, launch_frames(n, pd, pcm, L, S, 0, C, sk, st));
+    HIPCHK(e, launch_finalize(e->d_hist, (int64_t)cells, m, e->d_lut, db, rgba, index, st));
+    return EMSPEC_OK;
+}
+
+int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                 const emspec_out* out) {
+    if (!e || !pcm || !out) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t C = emspec_num_columns(L, n, hop);
+    const size_t cells = (size_t)S * C * e->cfg.rows;
+    const size_t b_pcm = (size_t)S * L * sizeof(float);
+    const size_t b_db = out->db ? cells * 4 : 0, b_rgba = out->rgba ? cells * 4 : 0, b_idx = out->index ? cells : 0;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, al(b_pcm) + al(b_db) + al(b_rgba) + al(b_idx) + 256))) return rc;
+    char* base = e->d_stage;
+    float* d_pcm = (float*)base; base += al(b_pcm);
+    float* d_db = b_db ? (float*)base : nullptr; base += al(b_db);
+    uint8_t* d_rgba = b_rgba ? (uint8_t*)base : nullptr; base += al(b_rgba);
+    uint8_t* d_idx = b_idx ? (uint8_t*)base : nullptr;
+    HIPCHK(e, hipMemcpyAsync(d_pcm, pcm, b_pcm, hipMemcpyHostToDevice, e->stream));
+    if ((rc = emspec_batch_device(e, d_pcm, S, L, n, hop, reassign, d_db, d_rgba, d_idx, e->stream))) return rc;
+    if (b_db) HIPCHK(e, hipMemcpyAsync(out->db, d_db, b_db, hipMemcpyDeviceToHost, e->stream));
+    if (b_rgba) HIPCHK(e, hipMemcpyAsync(out->rgba, d_rgba, b_rgba, hipMemcpyDeviceToHost, e->stream));
+    if (b_idx) HIPCHK(e, hipMemcpyAsync(out->index, d_idx, b_idx, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
+int emspec_parity_dump_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                              int32_t reassign, int64_t frame0, int64_t nframes, float* power, int32_t* col,
+                              int32_t* row, void* hip_stream) {
+    if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    const int64_t C = emspec_num_columns(L, n, hop);
+    if (S < 1 || S > 65535 || frame0 < 0 || nframes < 0 || frame0 + nframes > C)
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "frame range outside the stream");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    FrameSinks sk;
+    sk.power = power; sk.col = col; sk.row = row;
+    HIPCHK(e, launch_frames(n, pd, pcm, L, S, frame0, nframes, sk, st));
+    return EMSPEC_OK;
+}
+
+int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                       int32_t reassign, int64_t frame0, int64_t nframes, float* power, int32_t* col, int32_t* row) {
+    if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t nb = (size_t)S * nframes * (n / 2 + 1);
+    const size_t b_pcm = (size_t)S * L * sizeof(float);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, al(b_pcm) + 3 * al(nb * 4) + 256))) return rc;
+    char* base = e->d_stage;
+    float* d_pcm = (float*)base; base += al(b_pcm);
+    float* d_pw = (float*)base; base += al(nb * 4);
+    int32_t* d_col = (int32_t*)base; base += al(nb * 4);
+    int32_t* d_row = (int32_t*)base;
+    HIPCHK(e, hipMemcpyAsync(d_pcm, pcm, b_pcm, hipMemcpyHostToDevice, e->stream));
+    if ((rc = emspec_parity_dump_device(e, d_pcm, S, L, n, hop, reassign, frame0, nframes, d_pw, d_col, d_row, e->stream))) return rc;
+    HIPCHK(e, hipMemcpyAsync(power, d_pw, nb * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(col, d_col, nb * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(row, d_row, nb * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
+int emspec_reset(emspec_engine* e) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0;
+    e->st_fed = 0; e->st_emitted = 0;
+    return EMSPEC_OK;
+}
+
+// finalize ring slot of absolute column c (or the empty slot when c < 0), copy out, clear the slot
+static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_rgba) {
+    const int R = e->cfg.rows;
+    const int W = 2 * e->st_D + 1;
+    const int64_t slot = c < 0 ? W : c % W;
+    const DbMap m = db_map(e, e->st_n);
+    float* cells = e->d_ring + (size_t)slot * R;
+    HIPCHK(e, launch_finalize(cells, R, m, e->d_lut, out_db ? e->d_coldb : nullptr, out_rgba ? e->d_colrgba : nullptr,
+                              nullptr, e->stream));
+    if (out_db) HIPCHK(e, hipMemcpyAsync(out_db, e->d_coldb, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
+    if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba, e->d_colrgba, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
+    if (c >= 0) HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)R * 4, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
+int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, int32_t reassign, float* out_db,
+                  uint8_t* out_rgba, int32_t rows, int64_t* out_column) {
+    if (!e || !frame) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
+    reassign = reassign ? 1 : 0;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int R = e->cfg.rows;
+    if (e->st_reassign < 0) {
+        // first frame of a stream: set up the ring
+        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = latency(n, hop, reassign);
+        const int W = 2 * e->st_D + 1;
+        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_frame, &e->frame_bytes, (size_t)n * 4))) return rc;
+        if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
+        if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
+        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
+    } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign) {
+        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign changed mid-stream; call emspec_reset() first");
+    }
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    const int64_t j = e->st_fed;
+    HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+    FrameSinks sk;
+    sk.hist = e->d_ring;
+    sk.hist_slots = 2 * e->st_D + 1;
+    sk.total_cols = INT64_MAX;
+    sk.ring = 1;
+    sk.col_offset = j;   // the staged frame sits at offset 0 but is absolute frame j
+    HIPCHK(e, launch_frames(n, pd, e->d_frame, n, 1, 0, 1, sk, e->stream));
+    e->st_fed = j + 1;
+    const int64_t c = j - e->st_D;   // column completed by this frame
+    if (out_column) *out_column = c >= 0 ? c : -1;
+    if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
+    if (c >= 0) e->st_emitted = c + 1;
+    return EMSPEC_OK;
+}
+
+int emspec_column_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba, int32_t rows, int64_t* out_column) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
+    if (e->st_reassign < 0 || e->st_emitted >= e->st_fed) return fail(e, EMSPEC_ERR_STATE, "no pending column");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int64_t c = e->st_emitted;
+    if (out_column) *out_column = c;
+    int rc = emit_column(e, c, out_db, out_rgba);
+    if (rc) return rc;
+    e->st_emitted = c + 1;
+    return EMSPEC_OK;
+}
+
+}  // extern "C"

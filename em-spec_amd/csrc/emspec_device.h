@@ -1,0 +1,143 @@
+// emspec_device.h — device-side building blocks shared by every kernel.
+//
+// Arithmetic specification.  The reference source is private
+// (/root/reference/README.md:73), so there is no reference file:line for the
+// arithmetic; the stage list is SURVEY.md §8(a).  The operation order below IS
+// the specification that oracle/emspec_oracle.c's float32 bit model restates
+// on the CPU; compile with -ffp-contract=off so the only fused operations are
+// the explicit __builtin_fmaf calls.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace emspec {
+
+// Per-(N,hop,config) constants handed to every kernel by value.
+struct PlanDev {
+    const float2* tw;    // twiddle table, N/2 entries: (cos, -sin)(2*pi*q/N); tw[N/4] == (0,-1) exactly
+    const float* ebin;   // row edges in DFT-bin units, rows+1 entries, strictly increasing
+    int rows;            // R
+    int D;               // max |column shift| = ceil(N/(2*hop)) (0 when reassign is off)
+    int reassign;        // 0/1
+    int hop;
+    float tscale;        // (N/2)/hop : normalised time shift -> columns
+    float pfloor_abs;    // gate on |X_h|^2
+};
+
+struct DbMap {           // stage "dB + colour"
+    float scale;         // 32/(3 N^2) * gain^2 : full-scale sine -> 1.0
+    float lo;            // db_top - db_range
+    float inv_range;     // 1/db_range
+    float gate;          // gate_db
+};
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// canonical complex product d * w  (see oracle fft_dif_f32)
+__device__ __forceinline__ float2 cmul_tw(float2 d, float2 w) {
+    float t = d.y * w.y;
+    float u = d.y * w.x;
+    return make_float2(__builtin_fmaf(d.x, w.x, -t), __builtin_fmaf(d.x, w.y, u));
+}
+
+// LDS index padding for the in-place exchange buffer: one complex slot of pad
+// per 16 keeps the stride-2^b accesses of every pass off a single bank pair.
+__device__ __forceinline__ constexpr int padi(int p) { return p + (p >> 4); }
+template <int N> struct PaddedSize { static constexpr int value = N + (N >> 4); };
+
+// Radix-2 DIF stages S0 .. S0+R-1 of an N = 2^LOG2N point FFT, performed on the
+// 2^R values a thread holds in registers.  Register i is the element with
+// global index  p = hi*2^(B0+R) + i*2^B0 + lo,  B0 = LOG2N-S0-R.
+// Stage s pairs (p, p+m), m = N>>(s+1), twiddle index q = (p mod m) << s.
+template <int LOG2N, int S0, int R>
+__device__ __forceinline__ void fft_stages(float2 (&v)[1 << R], int lo, const float2* __restrict__ tw) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int B0 = LOG2N - S0 - R;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int mloc = 1 << (R - 1 - u);
+        const int s = S0 + u;
+#pragma unroll
+        for (int i = 0; i < (1 << R); ++i) {
+            if (i & mloc) continue;
+            float2 a = v[i], b = v[i + mloc];
+            v[i] = cadd(a, b);
+            float2 d = csub(a, b);
+            if constexpr (B0 == 0) {
+                // last pass: lo == 0, q is a compile-time constant
+                const int q = (i & (mloc - 1)) << s;
+                if (q == 0) v[i + mloc] = d;
+                else if (q == N / 4) v[i + mloc] = make_float2(d.y, -d.x);
+                else v[i + mloc] = cmul_tw(d, tw[q]);
+            } else {
+                const int q = (((i & (mloc - 1)) << B0) + lo) << s;
+                v[i + mloc] = cmul_tw(d, tw[q]);   // tw[0]=(1,-0), tw[N/4]=(0,-1): exact
+            }
+        }
+    }
+}
+
+// row = largest r in [0,R) with ebin[r] <= kh ; -1 unless ebin[0] <= kh < ebin[R].
+// Exact float compares against the table: identical to the oracle's binary search.
+__device__ __forceinline__ int row_lookup(const float* eb, int R, int wtop, float kh) {
+    if (!(kh >= eb[0]) || !(kh < eb[R])) return -1;
+    int lo = 0;
+    for (int w = wtop; w > 0; w >>= 1) {
+        int mid = lo + w;
+        if (mid < R && eb[mid] <= kh) lo = mid;
+    }
+    return lo;
+}
+
+struct BinOut { float power; int dcol; int row; };  // dcol relative to the frame's own column
+
+// Stages "Power + gate", "Reassign", "Index quantise" for bin k, from the six
+// spectrum samples around k and N-k (natural order, wrapped).
+//   zm,z0,zp = Z[k-1],Z[k],Z[k+1] ;  wm,w0,wp = Z[N-k+1],Z[N-k],Z[N-k-1]
+__device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* eb, int wtop, int k,
+                                               float2 zm, float2 z0, float2 zp,
+                                               float2 wm, float2 w0, float2 wp) {
+    // conjugate split, scaled by 2:  Y = Z[k] + conj Z[N-k],  T = -j (Z[k] - conj Z[N-k])
+    float ymr = zm.x + wm.x, ymi = zm.y - wm.y, tmr = zm.y + wm.y, tmi = wm.x - zm.x;
+    float y0r = z0.x + w0.x, y0i = z0.y - w0.y, t0r = z0.y + w0.y, t0i = w0.x - z0.x;
+    float ypr = zp.x + wp.x, ypi = zp.y - wp.y, tpr = zp.y + wp.y, tpi = wp.x - zp.x;
+    // spectral Hann identities, scaled by 8
+    float Ar = (y0r + y0r) - (ymr + ypr), Ai = (y0i + y0i) - (ymi + ypi);
+    float Br = (t0r + t0r) - (tmr + tpr), Bi = (t0i + t0i) - (tmi + tpi);
+    float Dr = ymr - ypr, Di = ymi - ypi;
+    float den = __builtin_fmaf(Ar, Ar, Ai * Ai);
+    BinOut o;
+    o.power = den * 0.015625f;
+    o.dcol = 0;
+    o.row = -1;
+    if (o.power >= pl.pfloor_abs && o.power <= 3.0e38f) {
+        if (pl.reassign) {
+            float numT = __builtin_fmaf(Br, Ar, Bi * Ai);
+            float numF = __builtin_fmaf(Dr, Ar, Di * Ai);
+            float inv = 1.0f / den;      // IEEE-correct divide (no fast-math)
+            float ts = numT * inv;
+            float ks = numF * inv;
+            float cf = __builtin_floorf(__builtin_fmaf(ts, pl.tscale, 0.5f));
+            if (__builtin_fabsf(cf) <= (float)pl.D) {
+                o.dcol = (int)cf;
+                o.row = row_lookup(eb, pl.rows, wtop, (float)k + ks);
+            }
+        } else {
+            o.row = row_lookup(eb, pl.rows, wtop, (float)k);
+        }
+    }
+    return o;
+}
+
+// stage "dB + colour" for one histogram cell
+__device__ __forceinline__ float cell_db(const DbMap& m, float e) {
+    return 10.0f * log10f(e * m.scale + 1e-20f);
+}
+__device__ __forceinline__ int cell_index(const DbMap& m, float db) {
+    float v = (db - m.lo) * m.inv_range;
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    if (db < m.gate) v = 0.0f;
+    return (int)(v * 255.0f + 0.5f);
+}
+
+}  // namespace emspec

@@ -1,0 +1,40 @@
+// emspec_launch.h — host-callable launchers of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "emspec_device.h"
+
+namespace emspec {
+
+// Where frames_kernel sends its per-bin results.
+struct FrameSinks {
+    // parity dump (all three or none): [stream][frame][K]
+    float* power = nullptr;
+    int32_t* col = nullptr;
+    int32_t* row = nullptr;
+    // histogram scatter (global float atomics): hist[stream][slots][rows]
+    float* hist = nullptr;
+    int64_t hist_slots = 0;    // slots per stream in `hist`
+    int64_t total_cols = 0;    // valid absolute columns are [0,total_cols)
+    int32_t ring = 0;          // !=0: slot = col % hist_slots (streaming ring), else slot = col
+    int64_t col_offset = 0;    // added to the frame index to get its absolute column (streaming)
+};
+
+bool supported_fft(int n);
+
+// One workgroup per frame: frames [frame0, frame0+nframes) of each of S streams.
+hipError_t launch_frames(int n, const PlanDev& pl, const float* pcm, int64_t L, int S,
+                         int64_t frame0, int64_t nframes, const FrameSinks& sinks, hipStream_t st);
+
+// hist cells -> dB / RGBA / palette index (any output may be null). ncells % 4 == 0.
+hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, const uint8_t* lut,
+                           float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
+
+// Fused batch path (LDS column ring): returns hipErrorNotSupported when (n,hop,rows)
+// has no fused specialisation; the caller then uses launch_frames + launch_finalize.
+hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
+                        const float* pcm, int64_t L, int S, int64_t total_cols,
+                        float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
+bool fused_supported(int n, int hop, int rows, int reassign);
+
+}  // namespace emspec

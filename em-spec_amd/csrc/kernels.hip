@@ -1,0 +1,194 @@
+// kernels.hip — hand-written gfx950 kernels of the reassigned-spectrogram path.
+//
+// Stage list: SURVEY.md §8(a).  No reference file:line can be cited — the
+// reference source is private (/root/reference/README.md:73).
+//
+//   frames_kernel<LOG2N>   one workgroup per frame: frame gather, packed FFT
+//                          (register radix-16 passes over an in-place LDS
+//                          buffer), conjugate split + spectral Hann identities,
+//                          reassignment, row lookup; results go to the parity
+//                          dump and/or a global-atomic histogram.  Generic in
+//                          N and hop; also serves the streaming per-frame call.
+//   finalize_kernel        histogram -> dB / RGBA / palette index.
+//   fused kernels          see fused.hip.inc (LDS column ring, batch path).
+#include "emspec_launch.h"
+
+namespace emspec {
+
+// ---------------------------------------------------------------------------
+// FFT passes over the in-place LDS buffer.  16 points per thread, T = N/16.
+// ---------------------------------------------------------------------------
+template <int LOG2N, int S0>
+__device__ __forceinline__ void fft_rest(float2* sm, int t, const float2* __restrict__ tw) {
+    constexpr int N = 1 << LOG2N, T = N / 16;
+    constexpr int REM = LOG2N - S0;
+    if constexpr (REM > 4) {
+        // middle pass: stages S0..S0+3, one group of 16 per thread, in place
+        constexpr int B0 = LOG2N - S0 - 4;
+        const int lo = t & ((1 << B0) - 1), hi = t >> B0;
+        const int base = (hi << (B0 + 4)) + lo;
+        float2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = sm[padi(base + (i << B0))];
+        fft_stages<LOG2N, S0, 4>(v, lo, tw);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sm[padi(base + (i << B0))] = v[i];
+        __syncthreads();
+        fft_rest<LOG2N, S0 + 4>(sm, t, tw);
+    } else {
+        // last pass: stages S0..LOG2N-1 (R = REM <= 4), G groups per thread;
+        // output rewritten in natural frequency order (unpadded) after a barrier.
+        constexpr int R = REM, G = 16 >> R;
+        float2 v[G][1 << R];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int g = t + T * gi;
+#pragma unroll
+            for (int i = 0; i < (1 << R); ++i) v[gi][i] = sm[padi((g << R) + i)];
+            fft_stages<LOG2N, S0, R>(v[gi], 0, tw);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const int g = t + T * gi;
+#pragma unroll
+            for (int i = 0; i < (1 << R); ++i) {
+                const unsigned p = (unsigned)((g << R) + i);
+                const unsigned k = __brev(p) >> (32 - LOG2N);
+                sm[k] = v[gi][i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
+    PlanDev pl, const float* __restrict__ pcm, int64_t L, int64_t frame0, int64_t nframes,
+    FrameSinks sk) {
+    constexpr int N = 1 << LOG2N, T = N / 16, K = N / 2 + 1;
+    extern __shared__ float4 smem4[];
+    float2* sm = reinterpret_cast<float2*>(smem4);
+    float* seb = reinterpret_cast<float*>(sm + PaddedSize<N>::value);
+    const int t = threadIdx.x;
+    const int64_t f = blockIdx.x;          // frame within the launch
+    const int s = blockIdx.y;              // stream
+    const int64_t j = frame0 + f;          // frame within the pcm buffer
+    const int64_t jcol = j + sk.col_offset; // its own absolute column
+
+    for (int r = t; r <= pl.rows; r += T) seb[r] = pl.ebin[r];
+
+    // stage "Frame gather" + packing z = x + j*ramp*x, ramp = (n-N/2)*(2/N) exact
+    const float* x = pcm + (size_t)s * L + j * pl.hop;
+    float2 v[16];
+    const float rs = 2.0f / (float)N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int n = t + T * i;
+        const float xv = x[n];
+        v[i] = make_float2(xv, xv * ((float)(n - N / 2) * rs));
+    }
+    // stage "STFT": first pass (stages 0..3) straight from registers
+    fft_stages<LOG2N, 0, 4>(v, t, pl.tw);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm[padi(t + T * i)] = v[i];
+    __syncthreads();
+    fft_rest<LOG2N, 4>(sm, t, pl.tw);
+
+    // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
+    int wtop = 1;
+    while (wtop * 2 < pl.rows) wtop *= 2;
+#pragma unroll 1
+    for (int i = 0; i < 9; ++i) {
+        const int k = t + T * i;
+        if (k > N / 2) break;
+        const float2 zm = sm[(k - 1) & (N - 1)], z0 = sm[k], zp = sm[k + 1];
+        const float2 wm = sm[(N - k + 1) & (N - 1)], w0 = sm[(N - k) & (N - 1)], wp = sm[N - k - 1];
+        const BinOut o = reassign_bin(pl, seb, wtop, k, zm, z0, zp, wm, w0, wp);
+        const int64_t col = jcol + o.dcol;
+        if (sk.power) {
+            const size_t idx = ((size_t)s * nframes + f) * K + k;
+            sk.power[idx] = o.power;
+            sk.col[idx] = (int32_t)col;
+            sk.row[idx] = o.row;
+        }
+        if (sk.hist && o.row >= 0 && col >= 0 && col < sk.total_cols) {
+            const int64_t slot = sk.ring ? (col % sk.hist_slots) : col;
+            atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
+        }
+    }
+}
+
+bool supported_fft(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
+
+template <int LOG2N>
+static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
+                                  int64_t nframes, const FrameSinks& sk, hipStream_t st) {
+    constexpr int N = 1 << LOG2N;
+    const size_t lds = (size_t)PaddedSize<N>::value * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_kernel<LOG2N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    // grid.x is limited to 2^31-1, grid.y to 65535
+    if (nframes <= 0 || S <= 0) return hipSuccess;
+    if (S > 65535 || nframes > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nframes, (unsigned)S), block(N / 16);
+    hipLaunchKernelGGL(frames_kernel<LOG2N>, grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    return hipGetLastError();
+}
+
+hipError_t launch_frames(int n, const PlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
+                         int64_t nframes, const FrameSinks& sk, hipStream_t st) {
+    switch (n) {
+        case 256: return launch_frames_t<8>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 512: return launch_frames_t<9>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 1024: return launch_frames_t<10>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 2048: return launch_frames_t<11>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 4096: return launch_frames_t<12>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 8192: return launch_frames_t<13>(pl, pcm, L, S, frame0, nframes, sk, st);
+        case 16384: return launch_frames_t<14>(pl, pcm, L, S, frame0, nframes, sk, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: 4 cells per thread, 16-byte loads/stores, grid-stride.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_kernel(const float4* __restrict__ hist, int64_t nquads, DbMap m,
+                                                       const uint32_t* __restrict__ lut, float4* __restrict__ db,
+                                                       uint4* __restrict__ rgba, uint32_t* __restrict__ index) {
+    __shared__ uint32_t slut[256];
+    slut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * 256) {
+        const float4 e = hist[q];
+        const float d0 = cell_db(m, e.x), d1 = cell_db(m, e.y), d2 = cell_db(m, e.z), d3 = cell_db(m, e.w);
+        const int i0 = cell_index(m, d0), i1 = cell_index(m, d1), i2 = cell_index(m, d2), i3 = cell_index(m, d3);
+        if (db) db[q] = make_float4(d0, d1, d2, d3);
+        if (rgba) rgba[q] = make_uint4(slut[i0], slut[i1], slut[i2], slut[i3]);
+        if (index) index[q] = (uint32_t)i0 | ((uint32_t)i1 << 8) | ((uint32_t)i2 << 16) | ((uint32_t)i3 << 24);
+    }
+}
+
+hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, const uint8_t* lut, float* db,
+                           uint8_t* rgba, uint8_t* index, hipStream_t st) {
+    if (ncells <= 0) return hipSuccess;
+    if (ncells % 4) return hipErrorInvalidValue;
+    const int64_t nquads = ncells / 4;
+    int64_t blocks = (nquads + 255) / 256;
+    if (blocks > 2048 * 4) blocks = 2048 * 4;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(hist), nquads, m, reinterpret_cast<const uint32_t*>(lut),
+                       reinterpret_cast<float4*>(db), reinterpret_cast<uint4*>(rgba),
+                       reinterpret_cast<uint32_t*>(index));
+    return hipGetLastError();
+}
+
+}  // namespace emspec
+
+#include "fused.hip.inc"

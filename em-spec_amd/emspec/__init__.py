@@ -1,0 +1,218 @@
+"""Python binding of libemspec's C ABI (include/emspec.h) via ctypes.
+
+Used by tests/, bench.py and __graft_entry__.py.  The production host side is
+the Node addon in em-spec_amd/js/; this module exposes the same calls for the
+Python tooling.  There is NO fallback: if libemspec.so is missing or no gfx950
+device is present, loading / Engine() raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)                 # em-spec_amd/
+LIB_PATH = os.path.join(ROOT, "libemspec.so")
+
+ABI_VERSION = 1
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5
+
+SYMBOLS = [
+    "emspec_default_config", "emspec_create", "emspec_destroy", "emspec_last_error", "emspec_set_colormap",
+    "emspec_num_columns", "emspec_latency_columns", "emspec_column", "emspec_column_flush", "emspec_reset",
+    "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
+    "emspec_get_tables", "emspec_device_arch",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("rows", C.c_int32), ("reserved0", C.c_int32),
+                ("sample_rate", C.c_float), ("fmin_hz", C.c_float), ("fmax_hz", C.c_float), ("gain", C.c_float),
+                ("db_top", C.c_float), ("db_range", C.c_float), ("gate_db", C.c_float), ("power_floor", C.c_float)]
+
+
+class Out(C.Structure):
+    _fields_ = [("db", C.c_void_p), ("rgba", C.c_void_p), ("index", C.c_void_p)]
+
+
+class EmspecError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"emspec error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libemspec.so (built in-tree by __graft_entry__.build()). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    lib.emspec_last_error.restype = C.c_char_p
+    lib.emspec_last_error.argtypes = [C.c_void_p]
+    lib.emspec_device_arch.restype = C.c_char_p
+    lib.emspec_device_arch.argtypes = [C.c_void_p]
+    lib.emspec_num_columns.restype = C.c_int64
+    lib.emspec_num_columns.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+    lib.emspec_latency_columns.restype = C.c_int32
+    lib.emspec_latency_columns.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    lib.emspec_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.emspec_destroy.argtypes = [C.c_void_p]
+    lib.emspec_destroy.restype = None
+    lib.emspec_reset.argtypes = [C.c_void_p]
+    lib.emspec_set_colormap.argtypes = [C.c_void_p, C.c_void_p]
+    lib.emspec_column.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.POINTER(C.c_int64)]
+    lib.emspec_column_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    lib.emspec_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(Out)]
+    lib.emspec_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emspec_parity_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emspec_parity_dump_device.argtypes = lib.emspec_parity_dump.argtypes + [C.c_void_p]
+    lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def default_config(**kw):
+    cfg = Config()
+    load().emspec_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def num_columns(L, n, hop):
+    return int(load().emspec_num_columns(L, n, hop))
+
+
+def latency_columns(n, hop, reassign=True):
+    return int(load().emspec_latency_columns(n, hop, int(bool(reassign))))
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Engine:
+    """One engine = one HIP device + stream (not thread-safe), see emspec.h."""
+
+    def __init__(self, cfg=None, **kw):
+        self._lib = load()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        h = C.c_void_p()
+        rc = self._lib.emspec_create(C.byref(self.cfg), C.byref(h))
+        if rc != OK:
+            raise EmspecError(rc, self._lib.emspec_last_error(None).decode())
+        self._h = h
+        self.rows = int(self.cfg.rows)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.emspec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise EmspecError(rc, self._lib.emspec_last_error(self._h).decode())
+
+    @property
+    def arch(self):
+        return self._lib.emspec_device_arch(self._h).decode()
+
+    def set_colormap(self, lut):
+        lut = np.ascontiguousarray(lut, np.uint8)
+        assert lut.shape == (256, 4)
+        self._chk(self._lib.emspec_set_colormap(self._h, _np_ptr(lut)))
+
+    def tables(self, n):
+        eb = np.empty(self.rows + 1, np.float32)
+        tw = np.empty(n, np.float32)
+        self._chk(self._lib.emspec_get_tables(self._h, n, _np_ptr(eb), _np_ptr(tw)))
+        return tw, eb
+
+    # -- batch, host buffers ------------------------------------------------
+    def batch(self, pcm, n, hop, reassign=True, want=("db",)):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        S, L = pcm.shape
+        Cn = num_columns(L, n, hop)
+        db = np.empty((S, Cn, self.rows), np.float32) if "db" in want else None
+        rgba = np.empty((S, Cn, self.rows, 4), np.uint8) if "rgba" in want else None
+        idx = np.empty((S, Cn, self.rows), np.uint8) if "index" in want else None
+        out = Out(_np_ptr(db), _np_ptr(rgba), _np_ptr(idx))
+        self._chk(self._lib.emspec_batch(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), C.byref(out)))
+        return {"db": db, "rgba": rgba, "index": idx}
+
+    # -- batch, device-resident torch tensors ---------------------------------
+    def batch_device(self, pcm_t, n, hop, reassign=True, db=None, rgba=None, index=None, stream=None):
+        """pcm_t: contiguous float32 CUDA tensor [S, L]; outputs: preallocated CUDA tensors or None.
+        Enqueues on `stream` (a torch.cuda.Stream; default: the current torch stream); does not synchronise."""
+        import torch
+        assert pcm_t.is_cuda and pcm_t.dtype == torch.float32 and pcm_t.is_contiguous() and pcm_t.dim() == 2
+        S, L = pcm_t.shape
+        st = stream if stream is not None else torch.cuda.current_stream(pcm_t.device)
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        for t in (db, rgba, index):
+            assert t is None or (t.is_cuda and t.is_contiguous())
+        self._chk(self._lib.emspec_batch_device(self._h, ptr(pcm_t), S, L, n, hop, int(bool(reassign)), ptr(db),
+                                                ptr(rgba), ptr(index), C.c_void_p(st.cuda_stream)))
+
+    # -- parity dump ------------------------------------------------------------
+    def parity_dump(self, pcm, n, hop, reassign=True, frame0=0, nframes=None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        S, L = pcm.shape
+        if nframes is None:
+            nframes = num_columns(L, n, hop) - frame0
+        K = n // 2 + 1
+        pw = np.empty((S, nframes, K), np.float32)
+        col = np.empty((S, nframes, K), np.int32)
+        row = np.empty((S, nframes, K), np.int32)
+        self._chk(self._lib.emspec_parity_dump(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), frame0,
+                                               nframes, _np_ptr(pw), _np_ptr(col), _np_ptr(row)))
+        return pw, col, row
+
+    # -- streaming: the renderer's computeSpectrogramColumn -------------------------
+    def column(self, frame, hop, reassign=True, want_rgba=False):
+        frame = np.ascontiguousarray(frame, np.float32)
+        n = frame.size
+        db = np.empty(self.rows, np.float32)
+        rgba = np.empty((self.rows, 4), np.uint8) if want_rgba else None
+        c = C.c_int64(-2)
+        self._chk(self._lib.emspec_column(self._h, _np_ptr(frame), n, hop, int(bool(reassign)), _np_ptr(db),
+                                          _np_ptr(rgba), self.rows, C.byref(c)))
+        return (db, rgba, int(c.value)) if want_rgba else (db, int(c.value))
+
+    def flush(self, want_rgba=False):
+        db = np.empty(self.rows, np.float32)
+        rgba = np.empty((self.rows, 4), np.uint8) if want_rgba else None
+        c = C.c_int64(-2)
+        self._chk(self._lib.emspec_column_flush(self._h, _np_ptr(db), _np_ptr(rgba), self.rows, C.byref(c)))
+        return (db, rgba, int(c.value)) if want_rgba else (db, int(c.value))
+
+    def reset(self):
+        self._chk(self._lib.emspec_reset(self._h))

@@ -1,0 +1,181 @@
+/*
+ * emspec.h — C ABI of libemspec, the MI355X reassigned-spectrogram engine.
+ *
+ * This is the drop-in boundary.  The reference
+ * (effree/EM-Spec) ships binaries only: its source is private
+ * (/root/reference/README.md:73), so NO reference FFI interface exists to
+ * cite.  The only interface the reference side names is the renderer call
+ *
+ *     computeSpectrogramColumn(audioFrame, fftSize, hop, reassign)
+ *
+ * (BASELINE.json:north_star).  Every entry point below is therefore
+ * [BUILD-DEFINED]; the comment on each one says which part of that call (or
+ * which documented feature of the reference: README.md line) it serves.
+ * INTEGRATION.md shows the N-API binding a maintainer adds on the
+ * Electron/Node side.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions cross this boundary;
+ *   - every function returns EMSPEC_OK (0) or a negative emspec_status;
+ *     the message is available from emspec_last_error();
+ *   - the caller owns every input and output buffer; buffers are borrowed
+ *     for the duration of the call only;
+ *   - one engine = one HIP device + one HIP stream; an engine is not
+ *     thread-safe, calls on one engine are serialised by the caller;
+ *   - there is NO CPU fallback: if no gfx950 device or no kernel image is
+ *     available emspec_create fails with EMSPEC_ERR_NO_DEVICE.
+ */
+#ifndef EMSPEC_H
+#define EMSPEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMSPEC_ABI_VERSION 1
+
+typedef enum emspec_status {
+    EMSPEC_OK = 0,
+    EMSPEC_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported N,hop */
+    EMSPEC_ERR_NO_DEVICE = -2,     /* no HIP device, or not gfx950 */
+    EMSPEC_ERR_HIP = -3,           /* a HIP runtime call failed (message has the HIP error) */
+    EMSPEC_ERR_OUT_OF_MEMORY = -4,
+    EMSPEC_ERR_STATE = -5          /* call sequence error (e.g. N/hop changed mid-stream without reset) */
+} emspec_status;
+
+/* Output selection bits for emspec_out / emspec_out_device. */
+#define EMSPEC_OUT_DB 1u     /* float32 dB per (column,row)               */
+#define EMSPEC_OUT_RGBA 2u   /* uint8[4] colour per (column,row)          */
+#define EMSPEC_OUT_INDEX 4u  /* uint8 palette index 0..255 per (column,row) */
+
+/*
+ * Engine configuration: the display-side settings the reference exposes as
+ * sliders (README.md:44-51, assets/settings.png) plus the analysis grid.
+ * All fields are plain scalars; zero-initialise then call
+ * emspec_default_config().
+ */
+typedef struct emspec_config {
+    int32_t abi_version;   /* must be EMSPEC_ABI_VERSION */
+    int32_t device;        /* HIP device ordinal */
+    int32_t rows;          /* R: log-frequency rows per column (64..4096), default 1024 */
+    int32_t reserved0;
+    float sample_rate;     /* Hz, default 48000 */
+    float fmin_hz;         /* lowest row edge, default 20 */
+    float fmax_hz;         /* highest row edge, default sample_rate/2 */
+    float gain;            /* linear amplitude gain before dB ("Gain", README.md:46) */
+    float db_top;          /* dB value mapped to palette index 255, default 0 */
+    float db_range;        /* dB span mapped onto the palette ("dB Range", README.md:45) */
+    float gate_db;         /* cells below this dB are drawn as index 0 ("Noise Gate", README.md:47) */
+    float power_floor;     /* bins with |X_h|^2 below this are not reassigned/accumulated */
+} emspec_config;
+
+typedef struct emspec_engine emspec_engine;
+
+/* Host-memory outputs of emspec_batch: any pointer may be NULL (not wanted).
+ * Layout of each: [streams][columns][rows] (+[4] for rgba), C order. */
+typedef struct emspec_out {
+    float* db;
+    uint8_t* rgba;
+    uint8_t* index;
+} emspec_out;
+
+/* Fill *cfg with the defaults listed above. */
+int emspec_default_config(emspec_config* cfg);
+
+/* Create an engine on cfg->device.  Serves: engine construction behind the
+ * renderer's first computeSpectrogramColumn call. */
+int emspec_create(const emspec_config* cfg, emspec_engine** out_engine);
+void emspec_destroy(emspec_engine* e);
+
+/* Last error message of this engine (or of the failed emspec_create when
+ * e == NULL).  Never NULL; valid until the next call on the same thread. */
+const char* emspec_last_error(const emspec_engine* e);
+
+/* Upload a 256-entry RGBA palette ("Color Map", README.md:15).  The default
+ * is the 5-stop gradient measured from assets/settings.png. */
+int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba256x4);
+
+/* Number of columns a stream of L samples yields: (L-n)/hop+1, or 0. */
+int64_t emspec_num_columns(int64_t L, int32_t n, int32_t hop);
+
+/* Time reassignment moves energy up to ceil(n/(2*hop)) columns either way,
+ * so the streaming call returns column j-D when fed frame j.  This is D. */
+int32_t emspec_latency_columns(int32_t n, int32_t hop, int32_t reassign);
+
+/*
+ * Streaming, one frame per call — THE call the renderer makes:
+ *   computeSpectrogramColumn(audioFrame, fftSize, hop, reassign)
+ * frame: n float32 samples (frame j of the stream = samples [j*hop, j*hop+n)).
+ * The engine keeps the pending-column ring on the device.  With D =
+ * emspec_latency_columns(), call number j (0-based) writes finished column
+ * j-D; for j < D the output is the empty column (all cells at the dB floor)
+ * and *out_column (if non-NULL) is set to -1.  out_db (rows floats) and
+ * out_rgba (rows*4 bytes) may each be NULL.
+ * Changing n/hop/reassign between calls without emspec_reset() is
+ * EMSPEC_ERR_STATE.
+ */
+int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop,
+                  int32_t reassign, float* out_db, uint8_t* out_rgba,
+                  int32_t rows, int64_t* out_column);
+
+/* Flush: emit the next of the D columns still pending after the last frame
+ * (feeds no new samples).  Returns EMSPEC_ERR_STATE when nothing is pending. */
+int emspec_column_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba,
+                        int32_t rows, int64_t* out_column);
+
+/* Drop all per-stream state (sample position, pending ring). */
+int emspec_reset(emspec_engine* e);
+
+/*
+ * Batched throughput entry point, host buffers: S streams of L samples
+ * (pcm[S][L], row-major) -> every finished column of every stream.
+ * Copies in, runs the fused column kernel, copies the selected outputs back.
+ */
+int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
+                 int32_t n, int32_t hop, int32_t reassign, const emspec_out* out);
+
+/*
+ * Same, device-resident: pcm and the outputs are device pointers on the
+ * engine's device; the kernels are enqueued on hip_stream (a hipStream_t
+ * passed as void*, NULL = the engine's own stream) and the call returns
+ * without synchronising.  Output pointers may be NULL.
+ */
+int emspec_batch_device(emspec_engine* e, const float* pcm_dev, int32_t S,
+                        int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                        float* db_dev, uint8_t* rgba_dev, uint8_t* index_dev,
+                        void* hip_stream);
+
+/*
+ * Parity dump: per-bin results of frames [frame0, frame0+nframes) of each of
+ * the S streams, before the histogram scatter.  K = n/2+1 bins per frame.
+ *   power[s][f][k] = |X_h[k]|^2          (float32)
+ *   col  [s][f][k] = absolute reassigned column index (int32)
+ *   row  [s][f][k] = log-frequency row, or -1 if the bin is gated/out of range
+ * Host pointers.  Used by the parity tests (exact col/row, 1e-4 on power).
+ */
+int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
+                       int32_t n, int32_t hop, int32_t reassign,
+                       int64_t frame0, int64_t nframes,
+                       float* power, int32_t* col, int32_t* row);
+
+/* Device-pointer form of the same (all five buffers on the device). */
+int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
+                              int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                              int64_t frame0, int64_t nframes,
+                              float* power_dev, int32_t* col_dev, int32_t* row_dev,
+                              void* hip_stream);
+
+/* Copy out the tables the kernels use for (n): row edges in bin units
+ * (rows+1 floats) and the twiddle table (n/2 complex = n floats, re,im
+ * interleaved).  Either pointer may be NULL.  For table-parity tests. */
+int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twiddle);
+
+/* Name of the device the engine runs on, e.g. "gfx950". */
+const char* emspec_device_arch(const emspec_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMSPEC_H */

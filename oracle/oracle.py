@@ -1,0 +1,130 @@
+"""ctypes loader for the CPU oracle (oracle/libemspec_oracle.so).
+
+TEST INFRASTRUCTURE ONLY (see emspec_oracle.h).  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+PARITY UNPINNED: no reference source or fixtures exist (/root/reference/README.md:73).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libemspec_oracle.so")
+
+
+class EoCfg(C.Structure):
+    _fields_ = [("n", C.c_int32), ("hop", C.c_int32), ("rows", C.c_int32), ("reassign", C.c_int32),
+                ("sample_rate", C.c_float), ("fmin_hz", C.c_float), ("fmax_hz", C.c_float),
+                ("gain", C.c_float), ("db_top", C.c_float), ("db_range", C.c_float),
+                ("gate_db", C.c_float), ("power_floor", C.c_float)]
+
+
+DEFAULTS = dict(rows=1024, sample_rate=48000.0, fmin_hz=20.0, fmax_hz=24000.0, gain=1.0,
+                db_top=0.0, db_range=80.0, gate_db=-80.0, power_floor=1e-14)
+
+
+def make_cfg(n, hop, reassign=True, **kw):
+    d = dict(DEFAULTS)
+    d.update(kw)
+    return EoCfg(n=n, hop=hop, rows=int(d["rows"]), reassign=int(bool(reassign)),
+                 sample_rate=d["sample_rate"], fmin_hz=d["fmin_hz"], fmax_hz=d["fmax_hz"], gain=d["gain"],
+                 db_top=d["db_top"], db_range=d["db_range"], gate_db=d["gate_db"], power_floor=d["power_floor"])
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "emspec_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libemspec_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.eo_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def num_columns(L, n, hop):
+    return (L - n) // hop + 1 if L >= n else 0
+
+
+def tables(cfg):
+    tw = np.empty(cfg.n, np.float32)
+    eb = np.empty(cfg.rows + 1, np.float32)
+    assert lib().eo_tables(C.byref(cfg), _p(tw, C.c_float), _p(eb, C.c_float)) == 0
+    return tw, eb
+
+
+def default_lut():
+    lut = np.empty((256, 4), np.uint8)
+    lib().eo_default_lut(_p(lut, C.c_uint8))
+    return lut
+
+
+def frames_f32(cfg, pcm, frame0, nframes):
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    K = cfg.n // 2 + 1
+    pw = np.empty((nframes, K), np.float32)
+    col = np.empty((nframes, K), np.int32)
+    row = np.empty((nframes, K), np.int32)
+    rc = lib().eo_frames_f32(C.byref(cfg), _p(pcm, C.c_float), C.c_int64(pcm.size), C.c_int64(frame0),
+                             C.c_int64(nframes), _p(pw, C.c_float), _p(col, C.c_int32), _p(row, C.c_int32))
+    assert rc == 0, rc
+    return pw, col, row
+
+
+def frames_f64(cfg, pcm, frame0, nframes):
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    K = cfg.n // 2 + 1
+    pw = np.empty((nframes, K), np.float64)
+    that = np.empty((nframes, K), np.float64)
+    khat = np.empty((nframes, K), np.float64)
+    col = np.empty((nframes, K), np.int32)
+    row = np.empty((nframes, K), np.int32)
+    rc = lib().eo_frames_f64(C.byref(cfg), _p(pcm, C.c_float), C.c_int64(pcm.size), C.c_int64(frame0),
+                             C.c_int64(nframes), _p(pw, C.c_double), _p(that, C.c_double),
+                             _p(khat, C.c_double), _p(col, C.c_int32), _p(row, C.c_int32))
+    assert rc == 0, rc
+    return pw, that, khat, col, row
+
+
+def hist_f32(cfg, pcm, threads=0):
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    S, L = pcm.shape
+    Cn = num_columns(L, cfg.n, cfg.hop)
+    hist = np.empty((S, Cn, cfg.rows), np.float32)
+    rc = lib().eo_hist_f32(C.byref(cfg), _p(pcm, C.c_float), C.c_int32(S), C.c_int64(L), _p(hist, C.c_float),
+                           C.c_int32(threads))
+    assert rc == 0, rc
+    return hist
+
+
+def batch_f32(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    S, L = pcm.shape
+    Cn = num_columns(L, cfg.n, cfg.hop)
+    db = np.empty((S, Cn, cfg.rows), np.float32) if "db" in want else None
+    rgba = np.empty((S, Cn, cfg.rows, 4), np.uint8) if "rgba" in want else None
+    idx = np.empty((S, Cn, cfg.rows), np.uint8) if "index" in want else None
+    if lut is not None:
+        lut = np.ascontiguousarray(lut, np.uint8)
+    rc = lib().eo_batch_f32(C.byref(cfg), _p(pcm, C.c_float), C.c_int32(S), C.c_int64(L), _p(lut, C.c_uint8),
+                            _p(db, C.c_float), _p(rgba, C.c_uint8), _p(idx, C.c_uint8), C.c_int32(threads))
+    assert rc == 0, rc
+    return db, rgba, idx
+
+
+def max_threads():
+    return lib().eo_max_threads()
