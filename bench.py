@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — reassigned spectrogram columns/s (4096-pt, hop 256, 48 kHz) on N MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic audio that is
+already resident in HBM: every rank turns its 64 streams x 2^22 samples
+(BASELINE.json configs[2]; configs[3] at N=8) into 64 x 16,369 finished columns
+(float32 dB + uint8 palette index per cell).  For N > 1 the streams shard
+across ranks with no data-path exchange; the only collective is the RCCL
+gather of the finished palette-index columns to rank 0 (north_star), issued
+per stream-chunk on a side stream so it overlaps the next chunk's compute.
+
+Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md §6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "em-spec_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_device(S, L, first_stream, device, fs=48000.0):
+    """Synthetic audio generated on the device (SURVEY.md §8d shape: 8 sinusoids + chirp +
+    noise at -60 dBFS + a click every 24000 samples), float32 in [-1,1]."""
+    out = torch.empty((S, L), dtype=torch.float32, device=device)
+    t = torch.arange(L, dtype=torch.float64, device=device) / fs
+    for s in range(S):
+        g = torch.Generator(device="cpu").manual_seed(1000 + first_stream + s)
+        u = torch.rand(32, generator=g, dtype=torch.float64)
+        x = torch.zeros(L, dtype=torch.float64, device=device)
+        for i in range(8):
+            f = 30.0 * (20000.0 / 30.0) ** float(u[i])
+            a = 10.0 ** (-40.0 * float(u[8 + i]) / 20.0)
+            x += a * torch.sin(2 * np.pi * f * t + 2 * np.pi * float(u[16 + i]))
+        f0 = 200.0 + 4000.0 * float(u[24])
+        rate = 4.0e4 * (0.25 + 0.75 * float(u[25]))
+        tt = torch.remainder(t, max(1e-3, min(L / fs, (20000.0 - f0) / rate)))
+        x += 0.25 * torch.sin(2 * np.pi * (f0 * tt + 0.5 * rate * tt * tt))
+        gd = torch.Generator(device=device).manual_seed(5000 + first_stream + s)
+        x += 1e-3 * torch.randn(L, generator=gd, dtype=torch.float32, device=device).double()
+        x[::24000] += 1.0
+        x /= max(1.0, float(x.abs().max()))
+        out[s] = x.float()
+    return out
+
+
+def cpu_baseline(n, hop, seconds_target=12.0):
+    """Time the CPU oracle (float32 bit model, oracle/emspec_oracle.c) on a bounded sample of the
+    same workload, all host cores (OpenMP over streams)."""
+    import oracle as O
+    from emspec import synth
+    cores = O.max_threads()
+    cfg = O.make_cfg(n, hop, True)
+    # calibrate on a small run, then size the sample for ~seconds_target
+    probe = synth.streams(cores, n + hop * 127)
+    t0 = time.perf_counter(); O.batch_f32(cfg, probe, want=("db", "index"), threads=cores); dt = time.perf_counter() - t0
+    rate = cores * 128 / dt
+    cols_per_stream = int(max(256, min(8192, rate * seconds_target / cores)))
+    L = n + hop * (cols_per_stream - 1)
+    base = synth.streams(1, L)
+    pcm = np.stack([np.roll(base[0], 977 * s) for s in range(cores)])
+    t0 = time.perf_counter(); O.batch_f32(cfg, pcm, want=("db", "index"), threads=cores); dt = time.perf_counter() - t0
+    return {"value": cores * cols_per_stream / dt, "unit": "columns/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} streams x {cols_per_stream} columns (N={n}, hop={hop}, reassign on), "
+                      f"oracle float32 bit model, OpenMP {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384"])
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
+    ap.add_argument("--log2-samples", type=int, default=22)
+    ap.add_argument("--chunks", type=int, default=4, help="stream-chunks per step (gather overlap, N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import emspec
+    if args.workload == "n16384":
+        n, hop = 16384, 512
+    else:
+        n, hop = 4096, 256
+    S = args.streams or (1 if args.workload == "single" else 64)
+    L = 1 << args.log2_samples
+    eng = emspec.Engine(device=local_rank)
+    R = eng.rows
+    C = emspec.num_columns(L, n, hop)
+    pcm = synth_device(S, L, rank * S, dev)
+    db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, C, R), dtype=torch.uint8, device=dev)
+
+    nch = max(1, min(args.chunks, S)) if world > 1 else 1
+    bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=dev) for _ in range(world)] for a, b in bounds]
+
+    cur = torch.cuda.current_stream(dev)
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(timed_i=None):
+        for ci, (a, b) in enumerate(bounds):
+            if timed_i is not None and ci == 0:
+                kev[timed_i][0].record(cur)
+            eng.batch_device(pcm[a:b], n, hop, True, db=db[a:b], index=idx[a:b], stream=cur)
+            if timed_i is not None and ci == nch - 1:
+                kev[timed_i][1].record(cur)
+            if world > 1:
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(ready)
+                    dist.gather(idx[a:b], gathered[ci] if rank == 0 else None, dst=0)
+        if world > 1:
+            cur.wait_stream(comm_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        cols_per_step = world * S * C
+        value = cols_per_step * args.steps / elapsed
+        # dominant-kernel roofline: algorithmic bytes per column for this output mode
+        # (4*hop in, + 4*R dB out, + R palette-index out)
+        bytes_per_col = 4 * hop + 4 * R + R
+        kms = [a.elapsed_time(b) for a, b in kev]           # HIP events on the launch stream
+        k_avg_ms = float(np.mean(kms))
+        achieved = S * C * bytes_per_col / (k_avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "reassigned spectrogram columns/sec (4096-pt, hop 256, 48 kHz)" if n == 4096 else
+                      f"reassigned spectrogram columns/sec ({n}-pt, hop {hop}, 48 kHz)",
+            "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} concurrent 48 kHz streams per GPU x 2^{args.log2_samples} samples, FFT {n}, "
+                                   f"hop {hop}, reassignment ON, {R} log-frequency rows, outputs float32 dB + uint8 "
+                                   f"palette index" + (f"; RCCL gather of the palette-index columns to rank 0 in "
+                                                       f"{nch} overlapped chunks" if world > 1 else ""),
+                       "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
+                       "parallelism": f"streams sharded {world} way(s)", "fused_kernel": bool(getattr(eng, "fused", lambda *_: None)(n, hop))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_column": bytes_per_col, "kernel_ms": k_avg_ms,
+                         "note": "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / "
+                                 "HIP-event duration of the column kernel(s) on the launch stream; PMC traffic: profiles/"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(n, hop)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
