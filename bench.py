@@ -179,7 +179,7 @@ def main():
                                    f"palette index" + (f"; RCCL gather of the palette-index columns to rank 0 in "
                                                        f"{nch} overlapped chunks" if world > 1 else ""),
                        "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
-                       "parallelism": f"streams sharded {world} way(s)", "fused_kernel": bool(getattr(eng, "fused", lambda *_: None)(n, hop))},
+                       "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_column": bytes_per_col, "kernel_ms": k_avg_ms,

@@ -225,6 +225,9 @@ void emspec_destroy(emspec_engine* e) {
 
 const char* emspec_last_error(const emspec_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
+int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign) {
+    return e && fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
+}
 
 int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba) {
     if (!e || !rgba) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
@@ -264,7 +267,7 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     if (rc) return rc;
     if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
     HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP default stream
     Plan* p;
     if ((rc = get_plan(e, n, &p))) return rc;
     const PlanDev pd = plan_dev(e, *p, hop, reassign);
@@ -325,7 +328,7 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm, int32_t S, int
     if (S < 1 || S > 65535 || frame0 < 0 || nframes < 0 || frame0 + nframes > C)
         return fail(e, EMSPEC_ERR_INVALID_ARG, "frame range outside the stream");
     HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP default stream
     Plan* p;
     if ((rc = get_plan(e, n, &p))) return rc;
     const PlanDev pd = plan_dev(e, *p, hop, reassign);

@@ -91,20 +91,28 @@ __device__ __forceinline__ int row_lookup(const float* eb, int R, int wtop, floa
 
 struct BinOut { float power; int dcol; int row; };  // dcol relative to the frame's own column
 
-// Stages "Power + gate", "Reassign", "Index quantise" for bin k, from the six
-// spectrum samples around k and N-k (natural order, wrapped).
-//   zm,z0,zp = Z[k-1],Z[k],Z[k+1] ;  wm,w0,wp = Z[N-k+1],Z[N-k],Z[N-k-1]
-__device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* eb, int wtop, int k,
-                                               float2 zm, float2 z0, float2 zp,
-                                               float2 wm, float2 w0, float2 wp) {
-    // conjugate split, scaled by 2:  Y = Z[k] + conj Z[N-k],  T = -j (Z[k] - conj Z[N-k])
-    float ymr = zm.x + wm.x, ymi = zm.y - wm.y, tmr = zm.y + wm.y, tmi = wm.x - zm.x;
-    float y0r = z0.x + w0.x, y0i = z0.y - w0.y, t0r = z0.y + w0.y, t0i = w0.x - z0.x;
-    float ypr = zp.x + wp.x, ypi = zp.y - wp.y, tpr = zp.y + wp.y, tpi = wp.x - zp.x;
+// conjugate split, scaled by 2:  Y = Z[k] + conj Z[N-k],  T = -j (Z[k] - conj Z[N-k])
+struct YT { float yr, yi, tr, ti; };
+__device__ __forceinline__ YT split_yt(float2 z, float2 w) {
+    YT o;
+    o.yr = z.x + w.x; o.yi = z.y - w.y; o.tr = z.y + w.y; o.ti = w.x - z.x;
+    return o;
+}
+
+struct ExactLookup {   // binary search over the edge table (LDS or global)
+    const float* eb; int R; int wtop;
+    __device__ __forceinline__ int operator()(float kh) const { return row_lookup(eb, R, wtop, kh); }
+};
+
+// Stages "Power + gate", "Reassign", "Index quantise" for bin k from the
+// split spectra at k-1, k, k+1.
+template <class Lookup>
+__device__ __forceinline__ BinOut reassign_core(const PlanDev& pl, const Lookup& lookup, int k,
+                                                const YT& m, const YT& c, const YT& p) {
     // spectral Hann identities, scaled by 8
-    float Ar = (y0r + y0r) - (ymr + ypr), Ai = (y0i + y0i) - (ymi + ypi);
-    float Br = (t0r + t0r) - (tmr + tpr), Bi = (t0i + t0i) - (tmi + tpi);
-    float Dr = ymr - ypr, Di = ymi - ypi;
+    float Ar = (c.yr + c.yr) - (m.yr + p.yr), Ai = (c.yi + c.yi) - (m.yi + p.yi);
+    float Br = (c.tr + c.tr) - (m.tr + p.tr), Bi = (c.ti + c.ti) - (m.ti + p.ti);
+    float Dr = m.yr - p.yr, Di = m.yi - p.yi;
     float den = __builtin_fmaf(Ar, Ar, Ai * Ai);
     BinOut o;
     o.power = den * 0.015625f;
@@ -120,18 +128,30 @@ __device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* e
             float cf = __builtin_floorf(__builtin_fmaf(ts, pl.tscale, 0.5f));
             if (__builtin_fabsf(cf) <= (float)pl.D) {
                 o.dcol = (int)cf;
-                o.row = row_lookup(eb, pl.rows, wtop, (float)k + ks);
+                o.row = lookup((float)k + ks);
             }
         } else {
-            o.row = row_lookup(eb, pl.rows, wtop, (float)k);
+            o.row = lookup((float)k);
         }
     }
     return o;
 }
 
+//   zm,z0,zp = Z[k-1],Z[k],Z[k+1] ;  wm,w0,wp = Z[N-k+1],Z[N-k],Z[N-k-1]
+__device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* eb, int wtop, int k,
+                                               float2 zm, float2 z0, float2 zp,
+                                               float2 wm, float2 w0, float2 wp) {
+    ExactLookup lk{eb, pl.rows, wtop};
+    return reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
+}
+
 // stage "dB + colour" for one histogram cell
 __device__ __forceinline__ float cell_db(const DbMap& m, float e) {
     return 10.0f * log10f(e * m.scale + 1e-20f);
+}
+// in-kernel variant: v_log_f32 (<= 1 ulp of log2) — within 1e-4 dB of cell_db
+__device__ __forceinline__ float cell_db_fast(const DbMap& m, float e) {
+    return 3.0102999566398120f * __log2f(e * m.scale + 1e-20f);
 }
 __device__ __forceinline__ int cell_index(const DbMap& m, float db) {
     float v = (db - m.lo) * m.inv_range;

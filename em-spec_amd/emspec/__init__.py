@@ -22,7 +22,7 @@ SYMBOLS = [
     "emspec_default_config", "emspec_create", "emspec_destroy", "emspec_last_error", "emspec_set_colormap",
     "emspec_num_columns", "emspec_latency_columns", "emspec_column", "emspec_column_flush", "emspec_reset",
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
-    "emspec_get_tables", "emspec_device_arch",
+    "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     lib.emspec_parity_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emspec_parity_dump_device.argtypes = lib.emspec_parity_dump.argtypes + [C.c_void_p]
+    lib.emspec_uses_fused.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
@@ -140,6 +141,9 @@ class Engine:
     @property
     def arch(self):
         return self._lib.emspec_device_arch(self._h).decode()
+
+    def fused(self, n, hop, reassign=True):
+        return bool(self._lib.emspec_uses_fused(self._h, n, hop, int(bool(reassign))))
 
     def set_colormap(self, lut):
         lut = np.ascontiguousarray(lut, np.uint8)

@@ -139,7 +139,7 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
 /*
  * Same, device-resident: pcm and the outputs are device pointers on the
  * engine's device; the kernels are enqueued on hip_stream (a hipStream_t
- * passed as void*, NULL = the engine's own stream) and the call returns
+ * passed as void*, NULL = the HIP default stream) and the call returns
  * without synchronising.  Output pointers may be NULL.
  */
 int emspec_batch_device(emspec_engine* e, const float* pcm_dev, int32_t S,
@@ -171,6 +171,10 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
  * (rows+1 floats) and the twiddle table (n/2 complex = n floats, re,im
  * interleaved).  Either pointer may be NULL.  For table-parity tests. */
 int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twiddle);
+
+/* 1 if emspec_batch/_device would run the fused LDS-ring kernel for this
+ * shape, 0 if the generic two-kernel path (global-atomic histogram). */
+int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign);
 
 /* Name of the device the engine runs on, e.g. "gfx950". */
 const char* emspec_device_arch(const emspec_engine* e);

@@ -101,3 +101,20 @@ def test_streaming_equals_batch(engine):
     engine.reset()
     got = np.stack([cols[c] for c in range(frames)])
     assert np.max(np.abs(got - ref)) < 8.7e-4
+
+
+@pytest.mark.parametrize("frames,S,reassign", [(203, 3, True), (64, 1, True), (5, 2, True), (130, 2, False), (1, 1, True)])
+def test_fused_segments_match_oracle(engine, frames, S, reassign):
+    """Fused LDS-ring kernel (N=4096, hop=256): several segments per stream, odd column counts,
+    fewer columns than the reassignment reach, reassign off."""
+    n, hop = 4096, 256
+    assert engine.fused(n, hop, reassign)
+    pcm = _pcm(n, hop, frames, S=S)
+    out = engine.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
+    cfg = O.make_cfg(n, hop, reassign)
+    odb, orgba, oidx = O.batch_f32(cfg, pcm)
+    assert out["db"].shape == odb.shape == (S, frames, 1024)
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
