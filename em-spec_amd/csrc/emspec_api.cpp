@@ -291,6 +291,36 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     return EMSPEC_OK;
 }
 
+// Diagnostic (not part of the product path): run the stamped build of the fused kernel and
+// return, per workgroup and wave, the cycles spent in each barrier-delimited phase.
+// cycles: [groups][waves][8 slots] uint64 on the HOST; *groups receives the workgroup count and
+// *waves the waves per workgroup (call with cycles == NULL first to size the buffer).
+int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S, int64_t L, int32_t n, int32_t hop,
+                              int32_t reassign, float* db_dev, uint8_t* index_dev, uint64_t* cycles, int64_t* groups,
+                              int32_t* waves) {
+    if (!e || !pcm_dev || !groups) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    if (!fused_supported(n, hop, e->cfg.rows, reassign)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused kernel for this shape");
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* p;
+    int rc;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    const DbMap m = db_map(e, n);
+    const int64_t C = emspec_num_columns(L, n, hop);
+    HIPCHK(e, launch_fused(n, pd, m, e->d_lut, pcm_dev, L, S, C, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
+    if (waves) *waves = fused_waves_per_group();
+    if (!cycles) return EMSPEC_OK;
+    unsigned long long* d = nullptr;
+    const size_t bytes = (size_t)(*groups) * fused_waves_per_group() * 8 * sizeof(unsigned long long);
+    HIPCHK(e, hipMalloc(&d, bytes));
+    hipError_t r = launch_fused(n, pd, m, e->d_lut, pcm_dev, L, S, C, db_dev, nullptr, index_dev, e->stream, d, groups);
+    if (r == hipSuccess) r = hipMemcpyAsync(cycles, d, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(d);
+    HIPCHK(e, r);
+    return EMSPEC_OK;
+}
+
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
                  const emspec_out* out) {
     if (!e || !pcm || !out) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");

@@ -145,6 +145,26 @@ __device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* e
     return reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
 }
 
+// Float accumulate into an LDS cell without ds_add_f32 (which retires about one lane
+// per 1.5 cycles on gfx950, measured: profiles/README.md).  Integer LDS atomics run at
+// full rate, so: exchange a NaN sentinel in (takes the cell), add in the VALU, store the
+// sum back (releases it).  A lane that reads the sentinel lost the race to another lane
+// or wave and retries; no lane holds a cell across a loop iteration, so the loop always
+// drains.  Result: the same float sum as an atomic add, in some order.
+__device__ __forceinline__ void lds_accumulate(float* cell, float p, bool want) {
+    unsigned* c = reinterpret_cast<unsigned*>(cell);
+    bool todo = want;
+    while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+        if (todo) {
+            const unsigned old = __hip_atomic_exchange(c, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old != 0xFFFFFFFFu) {
+                __hip_atomic_store(cell, __uint_as_float(old) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                todo = false;
+            }
+        }
+    }
+}
+
 // stage "dB + colour" for one histogram cell
 __device__ __forceinline__ float cell_db(const DbMap& m, float e) {
     return 10.0f * log10f(e * m.scale + 1e-20f);

@@ -34,7 +34,9 @@ hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, co
 // has no fused specialisation; the caller then uses launch_frames + launch_finalize.
 hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                         const float* pcm, int64_t L, int S, int64_t total_cols,
-                        float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
+                        float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
+                        unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
 bool fused_supported(int n, int hop, int rows, int reassign);
+int fused_waves_per_group();
 
 }  // namespace emspec

@@ -13,6 +13,8 @@
 //   fused kernels          see fused.hip.inc (LDS column ring, batch path).
 #include "emspec_launch.h"
 
+#include <cstdlib>
+
 namespace emspec {
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader-clock cycles of the fused kernel (stamped build, emspec_debug_phase_cycles)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "em-spec_amd")]
+import numpy as np
+import torch
+
+import emspec
+from bench import synth_device
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+L = 1 << 22
+n, hop = 4096, 256
+eng = emspec.Engine()
+lib = emspec.load()
+dev = torch.device("cuda", 0)
+pcm = synth_device(S, L, 0, dev)
+Cn = emspec.num_columns(L, n, hop)
+db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+idx = torch.empty((S, Cn, 1024), dtype=torch.uint8, device=dev)
+groups = C.c_int64(0)
+waves = C.c_int32(0)
+f = lib.emspec_debug_phase_cycles
+f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+              C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), None, C.byref(groups), C.byref(waves)) == 0
+torch.cuda.synchronize()
+cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
+assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
+names = ["passA+write", "barrier wait", "passB r/c/w", "passC r/c", "natural write", "bins+scatter", "finalize+shift", "-"]
+tot = cyc.sum(axis=2).astype(np.float64)
+print(f"groups {groups.value}; mean cycles per wave {tot.mean():.0f} (readcyclecounter units)")
+for i, nm in enumerate(names[:7]):
+    v = cyc[:, :, i].astype(np.float64)
+    print(f"  {nm:16s} {100 * v.sum() / tot.sum():5.1f} %   per-iteration {v.mean() / ((Cn / (groups.value / S) + 16) / 2):8.0f}")
