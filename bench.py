@@ -102,6 +102,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import emspec
+    from emspec import shard
     if args.workload == "n16384":
         n, hop = 16384, 512
     else:
@@ -111,7 +112,8 @@ def main():
     eng = emspec.Engine(device=local_rank)
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
-    pcm = synth_device(S, L, rank * S, dev)
+    first_stream, _ = shard.stream_shard(rank, world, world * S)
+    pcm = synth_device(S, L, first_stream, dev)
     db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
     idx = torch.empty((S, C, R), dtype=torch.uint8, device=dev)
 
@@ -137,7 +139,7 @@ def main():
                 ready.record(cur)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(ready)
-                    dist.gather(idx[a:b], gathered[ci] if rank == 0 else None, dst=0)
+                    shard.gather_columns_into(idx[a:b], gathered[ci] if rank == 0 else None, dst=0)
         if world > 1:
             cur.wait_stream(comm_stream)
 

@@ -291,6 +291,30 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     return EMSPEC_OK;
 }
 
+// Diagnostic (tests only): evaluate the fused kernels' hinted row lookup and the generic
+// binary search on `count` host values of k-hat for fft size n.
+int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_t count, int32_t* out_hint,
+                            int32_t* out_exact) {
+    if (!e || !kh || !out_hint || !out_exact || count < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, 1);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    float* d_kh = nullptr; int32_t *d_a = nullptr, *d_b = nullptr;
+    hipError_t r = hipMalloc(&d_kh, count * 4 + 4);
+    if (r == hipSuccess) r = hipMalloc(&d_a, count * 4 + 4);
+    if (r == hipSuccess) r = hipMalloc(&d_b, count * 4 + 4);
+    if (r == hipSuccess) r = hipMemcpyAsync(d_kh, kh, count * 4, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = launch_row_lookup_probe(p->d_ebin, e->cfg.rows, d_kh, count, d_a, d_b, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_hint, d_a, count * 4, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_exact, d_b, count * 4, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_kh); (void)hipFree(d_a); (void)hipFree(d_b);
+    HIPCHK(e, r);
+    return EMSPEC_OK;
+}
+
 // Diagnostic (not part of the product path): run the stamped build of the fused kernel and
 // return, per workgroup and wave, the cycles spent in each barrier-delimited phase.
 // cycles: [groups][waves][8 slots] uint64 on the HOST; *groups receives the workgroup count and

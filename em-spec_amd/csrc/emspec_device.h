@@ -89,6 +89,31 @@ __device__ __forceinline__ int row_lookup(const float* eb, int R, int wtop, floa
     return lo;
 }
 
+// Row lookup with a log2 hint and an exact +-1 correction against the table: same result as
+// the binary search.  The hint is off by at most one row (v_log_f32 error and the float32
+// rounding of the edges are both << a row, which is >= 0.67 % wide); the two exact compares
+// against the table decide.  Verified around every edge by tests/test_gpu_parity.py
+// (emspec_debug_row_lookup).  Garbage / NaN inputs map to row -1 through the range test.
+struct HintLookup {
+    const float* eb; int R; float e0, eR, l2e0, rscale;
+    __device__ __forceinline__ void init(const float* table, const float* gtable, int rows) {
+        eb = table; R = rows; e0 = gtable[0]; eR = gtable[rows];
+        l2e0 = log2f(e0);
+        rscale = (float)rows / (log2f(eR) - l2e0);
+    }
+    __device__ __forceinline__ bool in_range(float kh) const { return (kh >= e0) && (kh < eR); }
+    // row for an in-range kh (any kh is safe: the hint is clamped into the table)
+    __device__ __forceinline__ int row_unchecked(float kh) const {
+        int r0 = (int)((__log2f(kh) - l2e0) * rscale);
+        r0 = max(0, min(r0, R - 1));
+        const float lo = eb[r0], hi = eb[r0 + 1];
+        r0 += (kh >= hi) ? 1 : 0;
+        r0 -= (kh < lo) ? 1 : 0;
+        return r0;
+    }
+    __device__ __forceinline__ int operator()(float kh) const { return in_range(kh) ? row_unchecked(kh) : -1; }
+};
+
 struct BinOut { float power; int dcol; int row; };  // dcol relative to the frame's own column
 
 // conjugate split, scaled by 2:  Y = Z[k] + conj Z[N-k],  T = -j (Z[k] - conj Z[N-k])

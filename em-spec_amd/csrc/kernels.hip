@@ -191,6 +191,29 @@ hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, co
     return hipGetLastError();
 }
 
+// diagnostic: both row-lookup implementations on arbitrary inputs (tests only)
+__global__ void row_lookup_probe_kernel(const float* __restrict__ ebin, int rows, const float* __restrict__ kh,
+                                        int64_t count, int32_t* __restrict__ out_hint, int32_t* __restrict__ out_exact) {
+    extern __shared__ float4 smem4[];
+    float* seb = reinterpret_cast<float*>(smem4);
+    for (int r = threadIdx.x; r <= rows; r += blockDim.x) seb[r] = ebin[r];
+    __syncthreads();
+    HintLookup lk;
+    lk.init(seb, ebin, rows);
+    int wtop = 1;
+    while (wtop * 2 < rows) wtop *= 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        out_hint[i] = lk(kh[i]);
+        out_exact[i] = row_lookup(seb, rows, wtop, kh[i]);
+    }
+}
+hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh, int64_t count, int32_t* out_hint,
+                                   int32_t* out_exact, hipStream_t st) {
+    hipLaunchKernelGGL(row_lookup_probe_kernel, dim3(256), dim3(256), (size_t)(rows + 4) * 4, st, ebin, rows, kh, count,
+                       out_hint, out_exact);
+    return hipGetLastError();
+}
+
 }  // namespace emspec
 
 #include "fused.hip.inc"

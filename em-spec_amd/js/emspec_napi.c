@@ -1,0 +1,286 @@
+/*
+ * emspec_napi.c — thin N-API (raw node_api.h, N-API >= 4) shim over the C ABI of
+ * libemspec (include/emspec.h).  This is the process-internal FFI boundary of
+ * renderer JS -> this shim -> libemspec -> HIP kernels.
+ *
+ * The reference ships no addon, binding.gyp or IPC schema (its source is private,
+ * /root/reference/README.md:73); the only interface it names is the renderer call
+ * computeSpectrogramColumn(audioFrame, fftSize, hop, reassign) (BASELINE.json).
+ *
+ * Ownership: typed-array memory is borrowed for the duration of a call only.
+ * Errors: every failure throws a JS Error whose .code is the emspec_status name.
+ * There is no CPU path: without a gfx950 device create() throws EMSPEC_ERR_NO_DEVICE.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/emspec.h"
+
+#define NAPI_OK_OR_RETURN(env, call)                                     \
+    do {                                                                 \
+        if ((call) != napi_ok) {                                         \
+            napi_throw_error((env), "EMSPEC_NAPI", "N-API call failed: " #call); \
+            return NULL;                                                 \
+        }                                                                \
+    } while (0)
+
+static const char* status_name(int rc) {
+    switch (rc) {
+        case EMSPEC_ERR_INVALID_ARG: return "EMSPEC_ERR_INVALID_ARG";
+        case EMSPEC_ERR_NO_DEVICE: return "EMSPEC_ERR_NO_DEVICE";
+        case EMSPEC_ERR_HIP: return "EMSPEC_ERR_HIP";
+        case EMSPEC_ERR_OUT_OF_MEMORY: return "EMSPEC_ERR_OUT_OF_MEMORY";
+        case EMSPEC_ERR_STATE: return "EMSPEC_ERR_STATE";
+        default: return "EMSPEC_ERR_UNKNOWN";
+    }
+}
+
+static napi_value throw_status(napi_env env, emspec_engine* e, int rc) {
+    napi_throw_error(env, status_name(rc), emspec_last_error(e));
+    return NULL;
+}
+
+typedef struct { emspec_engine* e; } handle_t;
+
+static void finalize_handle(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    handle_t* h = (handle_t*)data;
+    if (h) { if (h->e) emspec_destroy(h->e); free(h); }
+}
+
+static int get_number_prop(napi_env env, napi_value obj, const char* name, double* out) {
+    bool has = false;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+    napi_value v;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_number) return 0;
+    return napi_get_value_double(env, v, out) == napi_ok;
+}
+
+static handle_t* get_handle(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((handle_t*)p)->e) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "not a live emspec engine handle");
+        return NULL;
+    }
+    return (handle_t*)p;
+}
+
+/* typed array of the wanted element type, or NULL data when the value is undefined/null */
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len, int optional) {
+    *data = NULL; *len = 0;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (optional && (t == napi_undefined || t == napi_null)) return 1;
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is) return 0;
+    napi_typedarray_type ty; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, v, &ty, len, data, &ab, &off) != napi_ok) return 0;
+    return ty == want;
+}
+
+/* create(config) -> external */
+static napi_value Create(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    emspec_config cfg;
+    emspec_default_config(&cfg);
+    if (argc >= 1) {
+        napi_valuetype t;
+        NAPI_OK_OR_RETURN(env, napi_typeof(env, argv[0], &t));
+        if (t == napi_object) {
+            double d;
+            if (get_number_prop(env, argv[0], "device", &d)) cfg.device = (int32_t)d;
+            if (get_number_prop(env, argv[0], "rows", &d)) cfg.rows = (int32_t)d;
+            if (get_number_prop(env, argv[0], "sampleRate", &d)) cfg.sample_rate = (float)d;
+            if (get_number_prop(env, argv[0], "fminHz", &d)) cfg.fmin_hz = (float)d;
+            if (get_number_prop(env, argv[0], "fmaxHz", &d)) cfg.fmax_hz = (float)d;
+            if (get_number_prop(env, argv[0], "gain", &d)) cfg.gain = (float)d;
+            if (get_number_prop(env, argv[0], "dbTop", &d)) cfg.db_top = (float)d;
+            if (get_number_prop(env, argv[0], "dbRange", &d)) cfg.db_range = (float)d;
+            if (get_number_prop(env, argv[0], "gateDb", &d)) cfg.gate_db = (float)d;
+            if (get_number_prop(env, argv[0], "powerFloor", &d)) cfg.power_floor = (float)d;
+        }
+    }
+    emspec_engine* e = NULL;
+    int rc = emspec_create(&cfg, &e);
+    if (rc != EMSPEC_OK) return throw_status(env, NULL, rc);
+    handle_t* h = (handle_t*)malloc(sizeof(handle_t));
+    if (!h) { emspec_destroy(e); napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
+    h->e = e;
+    napi_value ext;
+    if (napi_create_external(env, h, finalize_handle, NULL, &ext) != napi_ok) {
+        finalize_handle(env, h, NULL);
+        napi_throw_error(env, "EMSPEC_NAPI", "napi_create_external failed");
+        return NULL;
+    }
+    return ext;
+}
+
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void* p = NULL;
+    if (argc >= 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        handle_t* h = (handle_t*)p;
+        if (h->e) { emspec_destroy(h->e); h->e = NULL; }
+    }
+    return NULL;
+}
+
+static napi_value Rows(napi_env env, napi_callback_info info) {
+    /* rows(config) -> rows the engine would use (defaults applied) */
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    emspec_config cfg; emspec_default_config(&cfg);
+    double d;
+    if (argc >= 1 && get_number_prop(env, argv[0], "rows", &d)) cfg.rows = (int32_t)d;
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int32(env, cfg.rows, &r));
+    return r;
+}
+
+/* column(handle, frame:Float32Array, fftSize, hop, reassign, outDb?:Float32Array, outRgba?:Uint8Array) -> column index (-1 while priming) */
+static napi_value Column(napi_env env, napi_callback_info info) {
+    size_t argc = 7; napi_value argv[7];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 5) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "column(handle, frame, fftSize, hop, reassign[, outDb, outRgba])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* frame; size_t flen;
+    if (!get_typed(env, argv[1], napi_float32_array, &frame, &flen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "audioFrame must be a Float32Array"); return NULL; }
+    int32_t n, hop; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[4], &argv[4]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[4], &reassign));
+    if ((size_t)n != flen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "audioFrame.length must equal fftSize"); return NULL; }
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0;
+    if (argc > 5 && !get_typed(env, argv[5], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 6 && !get_typed(env, argv[6], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    int32_t rows = db ? (int32_t)dblen : (int32_t)(rgbalen / 4);
+    if (rgba && db && rgbalen != 4 * dblen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba.length must be 4*outDb.length"); return NULL; }
+    int64_t col = -1;
+    int rc = emspec_column(h->e, (const float*)frame, n, hop, reassign ? 1 : 0, (float*)db, (uint8_t*)rgba, rows, &col);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, col, &r));
+    return r;
+}
+
+/* flush(handle, outDb?, outRgba?) -> column index */
+static napi_value Flush(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 2) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "flush(handle, outDb[, outRgba])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0;
+    if (!get_typed(env, argv[1], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 2 && !get_typed(env, argv[2], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    int32_t rows = db ? (int32_t)dblen : (int32_t)(rgbalen / 4);
+    int64_t col = -1;
+    int rc = emspec_column_flush(h->e, (float*)db, (uint8_t*)rgba, rows, &col);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, col, &r));
+    return r;
+}
+
+static napi_value Reset(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    int rc = emspec_reset(h->e);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+/* batch(handle, pcm:Float32Array(S*L), S, L, fftSize, hop, reassign, outDb?, outRgba?, outIndex?) -> columns per stream */
+static napi_value Batch(napi_env env, napi_callback_info info) {
+    size_t argc = 10; napi_value argv[10];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 8) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "batch(handle, pcm, S, L, fftSize, hop, reassign, outDb[, outRgba, outIndex])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* pcm; size_t plen;
+    if (!get_typed(env, argv[1], napi_float32_array, &pcm, &plen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; int64_t L; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[3], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[6], &argv[6]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[6], &reassign));
+    if (S < 1 || L < 1 || (size_t)S * (size_t)L != plen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm.length must equal S*L"); return NULL; }
+    emspec_out out; memset(&out, 0, sizeof(out));
+    size_t l0 = 0, l1 = 0, l2 = 0; void *p0 = NULL, *p1 = NULL, *p2 = NULL;
+    if (!get_typed(env, argv[7], napi_float32_array, &p0, &l0, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 8 && !get_typed(env, argv[8], napi_uint8_array, &p1, &l1, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 9 && !get_typed(env, argv[9], napi_uint8_array, &p2, &l2, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outIndex must be a Uint8Array"); return NULL; }
+    int64_t C = emspec_num_columns(L, n, hop);
+    /* sizes are checked against rows implied by the first output given */
+    size_t cells = 0;
+    if (p0) cells = l0; else if (p1) cells = l1 / 4; else if (p2) cells = l2;
+    if (C <= 0 || cells == 0 || cells % ((size_t)S * (size_t)C) != 0 || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold S*columns*rows cells (rgba: 4 bytes per cell)");
+        return NULL;
+    }
+    out.db = (float*)p0; out.rgba = (uint8_t*)p1; out.index = (uint8_t*)p2;
+    int rc = emspec_batch(h->e, (const float*)pcm, S, L, n, hop, reassign ? 1 : 0, &out);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, C, &r));
+    return r;
+}
+
+static napi_value SetColormap(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* lut; size_t len;
+    if (argc < 2 || !get_typed(env, argv[1], napi_uint8_array, &lut, &len, 0) || len != 1024) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "colormap must be a Uint8Array(1024) of RGBA"); return NULL; }
+    int rc = emspec_set_colormap(h->e, (const uint8_t*)lut);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+static napi_value NumColumns(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int64_t L = 0; int32_t n = 0, hop = 0;
+    if (argc < 3) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "numColumns(L, fftSize, hop)"); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[0], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[1], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &hop));
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, emspec_num_columns(L, n, hop), &r));
+    return r;
+}
+
+static napi_value LatencyColumns(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int32_t n = 0, hop = 0; bool re = true;
+    if (argc < 2) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "latencyColumns(fftSize, hop[, reassign])"); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[0], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[1], &hop));
+    if (argc > 2) { NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[2], &argv[2])); NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[2], &re)); }
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int32(env, emspec_latency_columns(n, hop, re ? 1 : 0), &r));
+    return r;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+    napi_property_descriptor props[] = {
+        {"create", NULL, Create, NULL, NULL, NULL, napi_default, NULL},
+        {"destroy", NULL, Destroy, NULL, NULL, NULL, napi_default, NULL},
+        {"rows", NULL, Rows, NULL, NULL, NULL, napi_default, NULL},
+        {"column", NULL, Column, NULL, NULL, NULL, napi_default, NULL},
+        {"flush", NULL, Flush, NULL, NULL, NULL, napi_default, NULL},
+        {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
+        {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
+        {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
+        {"numColumns", NULL, NumColumns, NULL, NULL, NULL, napi_default, NULL},
+        {"latencyColumns", NULL, LatencyColumns, NULL, NULL, NULL, napi_default, NULL},
+    };
+    napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,53 @@
+'use strict';
+/* Node smoke test of the drop-in call on a GPU box: BASELINE config 1 (FFT 1024, hop 256,
+ * reassignment off) frame by frame, and config 2 shape (4096/256, reassignment on) against
+ * the batched entry point.  Exits non-zero on any mismatch.  Run: node test_emspec.js */
+const em = require('./index.js');
+
+function synth(L) {
+  const x = new Float32Array(L);
+  let s = 12345;
+  for (let i = 0; i < L; i++) {
+    s = (Math.imul(s, 1103515245) + 12345) | 0;
+    const noise = ((s >>> 8) / 16777216 - 0.5) * 2e-3;
+    x[i] = 0.5 * Math.sin(2 * Math.PI * 440 * i / 48000) + 0.25 * Math.sin(2 * Math.PI * (1000 + 2000 * i / 48000) * i / 48000) + noise;
+  }
+  x[3000] += 0.9;
+  return x;
+}
+
+function check(fftSize, hop, reassign, frames) {
+  const eng = em.createEngine({});
+  const L = fftSize + hop * (frames - 1);
+  const pcm = synth(L);
+  const R = eng.rows;
+  const ref = new Float32Array(frames * R);
+  const C = eng.computeColumns(pcm, 1, L, fftSize, hop, reassign, { db: ref });
+  if (C !== frames) throw new Error('column count ' + C);
+  const D = em.latencyColumns(fftSize, hop, reassign);
+  const got = new Float32Array(frames * R);
+  let emitted = 0;
+  for (let j = 0; j < frames; j++) {
+    const col = eng.computeSpectrogramColumn(pcm.subarray(j * hop, j * hop + fftSize), fftSize, hop, reassign);
+    if (col.length !== R) throw new Error('column length');
+    if (j < D) { if (eng.lastColumn !== -1) throw new Error('priming column index'); continue; }
+    if (eng.lastColumn !== j - D) throw new Error('column index ' + eng.lastColumn);
+    got.set(col, (j - D) * R); emitted++;
+  }
+  for (let k = 0; k < D; k++) { const col = eng.flush(); got.set(col, eng.lastColumn * R); emitted++; }
+  if (emitted !== frames) throw new Error('emitted ' + emitted);
+  let worst = 0;
+  for (let i = 0; i < got.length; i++) worst = Math.max(worst, Math.abs(got[i] - ref[i]));
+  if (!(worst < 8.7e-4)) throw new Error('streaming vs batch dB mismatch ' + worst);
+  let threw = false;
+  try { eng.flush(); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
+  if (!threw) throw new Error('flush past the end must throw EMSPEC_ERR_STATE');
+  eng.destroy();
+  return worst;
+}
+
+const w1 = check(1024, 256, false, 40);
+const w2 = check(4096, 256, true, 40);
+const col = em.computeSpectrogramColumn(new Float32Array(1024), 1024, 256, false);
+if (col.length !== 1024) throw new Error('module-level call');
+console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2));

@@ -1,0 +1,94 @@
+"""CPU: the C ABI loads, exports every symbol include/emspec.h declares, and fails loudly
+without a GPU (there is no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+import torch
+
+import emspec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "emspec.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(emspec_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    lib = emspec.load()
+    names = declared_functions()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/emspec.h but not exported by libemspec.so"
+    assert set(emspec.SYMBOLS) <= set(names)
+
+
+def test_library_has_gfx950_code_object():
+    out = subprocess.run(["strings", "-n", "6", emspec.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    assert "fused4096" in out and "frames_kernel" in out
+
+
+def test_pure_functions():
+    assert emspec.num_columns(1 << 22, 4096, 256) == 16369
+    assert emspec.num_columns(4095, 4096, 256) == 0
+    assert emspec.latency_columns(4096, 256, True) == 8
+    assert emspec.latency_columns(16384, 512, True) == 16
+    assert emspec.latency_columns(4096, 256, False) == 0
+    cfg = emspec.default_config()
+    assert (cfg.rows, cfg.abi_version) == (1024, 1)
+    assert cfg.sample_rate == 48000.0 and cfg.fmin_hz == 20.0
+
+
+@pytest.mark.skipif(HAS_GPU, reason="checks the no-GPU failure mode")
+def test_create_fails_loudly_without_gpu():
+    with pytest.raises(emspec.EmspecError) as ei:
+        emspec.Engine()
+    assert ei.value.code == emspec.ERR_NO_DEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_create_rejects_bad_config():
+    lib = emspec.load()
+    h = C.c_void_p()
+    cfg = emspec.default_config(rows=1000 + 1)
+    assert lib.emspec_create(C.byref(cfg), C.byref(h)) == emspec.ERR_INVALID_ARG
+    cfg = emspec.default_config(abi_version=99)
+    assert lib.emspec_create(C.byref(cfg), C.byref(h)) == emspec.ERR_INVALID_ARG
+    assert b"abi_version" in lib.emspec_last_error(None)
+
+
+def test_product_does_not_link_the_oracle():
+    """The oracle is test infrastructure: libemspec.so and the addon must not depend on it."""
+    out = subprocess.run(["ldd", emspec.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(ROOT, "em-spec_amd")):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".inc", ".c", ".js", ".py")):
+                for line in open(os.path.join(root, f), errors="ignore"):
+                    code = line.split("//")[0]
+                    bad = ("#include" in code and "oracle" in code) or "libemspec_oracle" in code \
+                        or re.match(r"\s*(import|from)\s+(oracle|ref_numpy)\b", code)
+                    assert not bad, (f, line)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_node_addon_loads_and_reports_errors():
+    js = os.path.join(ROOT, "em-spec_amd", "js")
+    if not os.path.exists(os.path.join(js, "emspec.node")):
+        pytest.skip("addon not built")
+    code = ("const m=require('./index.js');"
+            "if(m.numColumns(4194304,4096,256)!==16369) process.exit(2);"
+            "if(m.latencyColumns(4096,256,true)!==8) process.exit(3);"
+            "try{m.createEngine({rows:1001});process.exit(4);}catch(e){if(e.code!=='EMSPEC_ERR_INVALID_ARG')process.exit(5);}"
+            + ("" if HAS_GPU else
+               "try{m.createEngine({});process.exit(6);}catch(e){if(e.code!=='EMSPEC_ERR_NO_DEVICE')process.exit(7);}"))
+    r = subprocess.run(["node", "-e", code], cwd=js, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)

@@ -118,3 +118,96 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign):
     d = np.abs(out["index"].astype(int) - oidx.astype(int))
     assert d.max() <= 1 and np.mean(d != 0) < 1e-3
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
+
+
+def test_hinted_row_lookup_equals_binary_search(engine):
+    """The fused kernels find the log-frequency row with a log2 hint + exact table compares.
+    Sweep every table edge with its float32 neighbours (+-1, +-2 ulp), row midpoints, values
+    just outside the table, zeros, negatives, inf and NaN: must equal the binary search."""
+    import ctypes as C
+    import emspec
+    lib = emspec.load()
+    f = lib.emspec_debug_row_lookup
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    for n in (1024, 4096, 16384):
+        _, eb = engine.tables(n)
+        vals = [eb]
+        for k in (1, 2):
+            up, dn = eb.copy(), eb.copy()
+            for _ in range(k):
+                up = np.nextafter(up, np.float32(np.inf)); dn = np.nextafter(dn, np.float32(-np.inf))
+            vals += [up, dn]
+        vals.append((0.5 * (eb[:-1].astype(np.float64) + eb[1:])).astype(np.float32))
+        rng = np.random.default_rng(n)
+        vals.append(np.exp(rng.uniform(np.log(eb[0] * 0.5), np.log(eb[-1] * 2.0), 200000)).astype(np.float32))
+        vals.append(np.array([0.0, -0.0, -1.0, 1e-30, 1e30, np.inf, -np.inf, np.nan], np.float32))
+        kh = np.ascontiguousarray(np.concatenate(vals), np.float32)
+        a = np.empty(kh.size, np.int32); b = np.empty(kh.size, np.int32)
+        assert f(engine._h, n, kh.ctypes.data, kh.size, a.ctypes.data, b.ctypes.data) == 0
+        assert np.array_equal(a, b), f"n={n}: {np.sum(a != b)} mismatches"
+        ref = np.searchsorted(eb, kh, side="right") - 1
+        ok = (kh >= eb[0]) & (kh < eb[-1])
+        assert np.array_equal(b[ok], ref[ok]) and np.all(b[~ok] == -1)
+
+
+def test_error_paths(engine):
+    import emspec
+    with pytest.raises(emspec.EmspecError) as ei:
+        engine.batch(np.zeros((1, 5000), np.float32), 3000, 256)       # unsupported fft size
+    assert ei.value.code == emspec.ERR_INVALID_ARG
+    with pytest.raises(emspec.EmspecError):
+        engine.batch(np.zeros((1, 100), np.float32), 4096, 256)        # shorter than one frame
+    engine.reset()
+    engine.column(np.zeros(1024, np.float32), 256, True)
+    with pytest.raises(emspec.EmspecError) as ei:
+        engine.column(np.zeros(4096, np.float32), 256, True)           # shape change mid-stream
+    assert ei.value.code == emspec.ERR_STATE
+    engine.reset()
+
+
+def test_full_size_properties(engine):
+    """BASELINE config 2 at full size (1 stream x 2^22 samples -> 16,369 columns), checked through
+    size-independent properties: (i) linearity of the energy histogram in the input power
+    (x -> 2x adds 20 log10 2 dB to every non-empty cell), (ii) time-shift covariance (delaying the
+    input by k hops shifts the columns by k), (iii) the column total tracks the frame energy."""
+    import torch
+    n, hop = 4096, 256
+    L = 1 << 22
+    pcm = synth.stream(7, L)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pcm)[None].to(dev)
+    Cn = (L - n) // hop + 1
+    db1 = torch.empty((1, Cn, 1024), dtype=torch.float32, device=dev)
+    db2 = torch.empty_like(db1)
+    engine.batch_device(x, n, hop, True, db=db1)
+    engine.batch_device((0.5 * x).contiguous(), n, hop, True, db=db2)
+    torch.cuda.synchronize()
+    assert Cn == 16369
+    live = db1 > -100      # well above the power floor (-142 dB), whose gate is not scale-invariant
+    d = (db1 - db2)[live]
+    assert torch.all(torch.abs(d - 20 * np.log10(2.0)) < 2e-3)        # scaling by 1/2 is exact in float32
+    k = 5
+    xs = torch.zeros_like(x)
+    xs[0, k * hop:] = x[0, :L - k * hop]
+    db3 = torch.empty_like(db1)
+    engine.batch_device(xs, n, hop, True, db=db3)
+    torch.cuda.synchronize()
+    a = db1[0, 40:Cn - 40 - k]
+    b = db3[0, 40 + k:Cn - 40]
+    assert torch.max(torch.abs(a - b)) < 1e-3
+    # energy conservation: sum over rows of a column's linear energy ~ Parseval of its frames (loose, in dB)
+    e_cols = torch.pow(10.0, db1[0] / 10).sum(dim=1).cpu().numpy()
+    assert np.isfinite(e_cols).all() and e_cols.max() < 10.0 and np.median(e_cols) > 1e-6
+
+
+def test_node_addon_on_gpu():
+    """The renderer-side call through the N-API addon, when node exists on the box."""
+    import os
+    import shutil
+    import subprocess
+    js = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "em-spec_amd", "js")
+    if shutil.which("node") is None or not os.path.exists(os.path.join(js, "emspec.node")):
+        pytest.skip("node or the built addon is not available on this box")
+    r = subprocess.run(["node", "test_emspec.js"], cwd=js, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "node addon ok" in r.stdout

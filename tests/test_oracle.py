@@ -1,0 +1,163 @@
+"""CPU: the oracle itself.  Pins the C oracle (float64 textbook method and float32 bit model)
+against (i) the committed golden fixtures made by the independent numpy formulation,
+(ii) that formulation run live, (iii) analytic known-answer tests.
+The reference's own outputs are not available (private source): parity is UNPINNED with
+respect to the reference, and these tests say so by construction."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import ref_numpy as RN
+from emspec import synth
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+FS = 48000.0
+
+
+def test_golden_files_present():
+    assert len(GOLD) >= 4
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_f64_oracle_matches_golden(path):
+    g = np.load(path)
+    n, hop, f0, fr, re = int(g["n"]), int(g["hop"]), int(g["frame0"]), int(g["frames"]), bool(g["reassign"])
+    cfg = O.make_cfg(n, hop, re)
+    p, that, khat, col, row = O.frames_f64(cfg, g["pcm"], f0, fr)
+    assert np.allclose(p, g["power"], rtol=1e-9, atol=1e-18)
+    assert np.max(np.abs(that - g["that"])) < 1e-4
+    assert np.max(np.abs(khat - g["khat"])) < 1e-6
+    assert np.mean(col != g["col"]) < 1e-4 and np.mean(row != g["row"]) < 1e-4
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_f32_bit_model_matches_golden(path):
+    """The float32 bit model (what the kernels compute) against the float64 vectors:
+    power within 1e-4 for bins within 60 dB of the frame maximum, indices equal except
+    for rare bins that sit on a cell edge."""
+    g = np.load(path)
+    n, hop, f0, fr, re = int(g["n"]), int(g["hop"]), int(g["frame0"]), int(g["frames"]), bool(g["reassign"])
+    cfg = O.make_cfg(n, hop, re)
+    p, col, row = O.frames_f32(cfg, g["pcm"], f0, fr)
+    strong = g["power"] >= g["power"].max(axis=1, keepdims=True) * 1e-6
+    rel = np.abs(p - g["power"]) / np.maximum(g["power"], 1e-300)
+    assert rel[strong].max() < 1e-4
+    valid = g["row"] >= 0
+    assert np.mean(row[valid] != g["row"][valid]) < 2e-3
+    assert np.mean(col[valid] != g["col"][valid]) < 2e-3
+
+
+@pytest.mark.parametrize("n,hop", [(256, 64), (1024, 256), (2048, 512), (4096, 256), (8192, 1024)])
+def test_f64_oracle_matches_numpy_live(n, hop):
+    pcm = synth.stream(40 + n % 7, n + hop * 9)
+    cfg = O.make_cfg(n, hop, True)
+    p, that, khat, col, row = O.frames_f64(cfg, pcm, 2, 5)
+    r = RN.reassign_frames(pcm, n, hop, 2, 5)
+    assert np.allclose(p, r["power"], rtol=1e-9, atol=1e-18)
+    assert np.max(np.abs(khat - r["khat"])) < 1e-6
+    assert np.mean(row != r["row"]) < 1e-4
+
+
+def test_kat_stationary_sine():
+    n, hop = 4096, 256
+    t = np.arange(n + hop * 4)
+    x = np.cos(2 * np.pi * 1234.567 * t / FS + 0.3).astype(np.float32)
+    cfg = O.make_cfg(n, hop, True)
+    p, that, khat, col, row = O.frames_f64(cfg, x, 0, 2)
+    kp = int(round(1234.567 * n / FS))
+    assert np.max(np.abs(khat[:, kp - 2:kp + 3] * FS / n - 1234.567)) < 5e-3     # f-hat at the true frequency
+    assert np.max(np.abs(that[0, kp - 2:kp + 3] - n / 2)) < 1e-3                 # t-hat at the frame centre
+    tw, eb = O.tables(cfg)
+    expect_row = np.searchsorted(eb, np.float32(1234.567 * n / FS), side="right") - 1
+    p32, c32, r32 = O.frames_f32(cfg, x, 0, 2)
+    assert np.all(r32[:, kp - 2:kp + 3] == expect_row) and np.all(c32[0, kp - 2:kp + 3] == 0)
+
+
+def test_kat_impulse():
+    n, hop = 4096, 256
+    x = np.zeros(n + hop * 4, np.float32)
+    x[2500] = 1.0
+    cfg = O.make_cfg(n, hop, True, power_floor=0.0)
+    p, that, khat, col, row = O.frames_f64(cfg, x, 0, 1)
+    assert np.max(np.abs(that - 2500.0)) < 1e-6
+    expect = int(np.floor((2500 - n / 2) / hop + 0.5))
+    assert col.min() == col.max() == expect
+    p32, c32, r32 = O.frames_f32(cfg, x, 0, 1)
+    assert c32.min() == c32.max() == expect
+
+
+def test_kat_linear_chirp():
+    n, hop = 4096, 256
+    t = np.arange(n + hop) / FS
+    f0, rate = 2000.0, 4.0e4
+    x = np.sin(2 * np.pi * (f0 * t + 0.5 * rate * t * t)).astype(np.float32)
+    cfg = O.make_cfg(n, hop, True)
+    p, that, khat, col, row = O.frames_f64(cfg, x, 0, 1)
+    strong = p[0] > p[0].max() * 1e-3
+    fhat = khat[0][strong] * FS / n
+    line = f0 + rate * that[0][strong] / FS
+    assert np.max(np.abs(fhat - line)) < 0.05      # (t-hat, f-hat) lies on the chirp's line
+
+
+def test_packed_fft_identity():
+    """x + j*ramp*x in one complex FFT == two real FFTs; spectral Hann identity == time-domain Hann."""
+    n = 1024
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n)
+    i = np.arange(n)
+    ramp = (i - n / 2) / (n / 2)
+    Z = np.fft.fft(x + 1j * ramp * x)
+    Zm = np.conj(np.roll(Z[::-1], 1))
+    Y = (Z + Zm) / 2
+    T = (Z - Zm) / 2j
+    assert np.allclose(Y, np.fft.fft(x), atol=1e-9) and np.allclose(T, np.fft.fft(ramp * x), atol=1e-9)
+    h = 0.5 - 0.5 * np.cos(2 * np.pi * i / n)
+    Xh = 0.5 * Y - 0.25 * (np.roll(Y, 1) + np.roll(Y, -1))
+    assert np.allclose(Xh, np.fft.fft(x * h), atol=1e-9)
+    Xdh = (np.pi / n) * (np.roll(Y, 1) - np.roll(Y, -1)) / 2j
+    assert np.allclose(Xdh, np.fft.fft(x * (np.pi / n) * np.sin(2 * np.pi * i / n)), atol=1e-9)
+
+
+def test_tables_and_lut():
+    cfg = O.make_cfg(4096, 256, True)
+    tw, eb = O.tables(cfg)
+    assert np.all(np.diff(eb) > 0) and eb.size == 1025
+    assert np.isclose(eb[0], 20.0 * 4096 / FS) and np.isclose(eb[-1], 2048.0)
+    assert tw[0] == 1.0 and tw[2 * 1024] == 0.0 and tw[2 * 1024 + 1] == -1.0
+    lut = O.default_lut()
+    assert tuple(lut[0]) == (0, 0, 0, 255) and tuple(lut[255]) == (255, 255, 200, 255)
+    assert tuple(lut[64][:3]) == (80, 0, 80) or abs(int(lut[64][0]) - 80) <= 1
+
+
+def test_batch_pipeline_consistency():
+    """eo_batch_f32 == scatter of eo_frames_f32 + dB map, including edge drops and empty cells."""
+    n, hop, frames = 1024, 256, 20
+    pcm = synth.streams(2, n + hop * (frames - 1))
+    cfg = O.make_cfg(n, hop, True)
+    db, rgba, idx = O.batch_f32(cfg, pcm)
+    hist = O.hist_f32(cfg, pcm)
+    for s in range(2):
+        p, col, row = O.frames_f32(cfg, pcm[s], 0, frames)
+        h = np.zeros((frames, 1024), np.float64)
+        ok = (row >= 0) & (col >= 0) & (col < frames)
+        np.add.at(h, (col[ok], row[ok]), p[ok].astype(np.float64))
+        assert np.allclose(hist[s], h, rtol=1e-5, atol=1e-12)
+    scale = 32.0 / (3.0 * n * n)
+    assert np.allclose(db, 10 * np.log10(hist.astype(np.float64) * scale + 1e-20), atol=1e-3)
+    assert db.min() == pytest.approx(-200.0, abs=1e-3)
+    assert np.array_equal(rgba, O.default_lut()[idx])
+
+
+def test_ragged_and_degenerate_inputs():
+    n, hop = 1024, 256
+    cfg = O.make_cfg(n, hop, True)
+    z = np.zeros((1, n + hop * 3), np.float32)           # silence: everything gated, empty columns
+    db, _, idx = O.batch_f32(cfg, z)
+    assert np.all(db == db.flat[0]) and np.all(idx == 0)
+    one = synth.streams(1, n)                             # exactly one frame
+    db1, _, _ = O.batch_f32(cfg, one)
+    assert db1.shape == (1, 1, 1024)
+    assert O.num_columns(n - 1, n, hop) == 0
