@@ -170,6 +170,16 @@ def main():
         kms = [a.elapsed_time(b) for a, b in kev]           # HIP events on the launch stream
         k_avg_ms = float(np.mean(kms))
         achieved = S * C * bytes_per_col / (k_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        if args.workload == "batch64" and S == 64 and args.log2_samples == 22:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[::-1]:
+                try:
+                    summ = json.load(open(f))["summary"]
+                    traffic, traffic_src = summ["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+                    break
+                except Exception:
+                    pass
         line = {
             "metric": "reassigned spectrogram columns/sec (4096-pt, hop 256, 48 kHz)" if n == 4096 else
                       f"reassigned spectrogram columns/sec ({n}-pt, hop {hop}, 48 kHz)",
@@ -183,7 +193,8 @@ def main():
                        "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
                        "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": S * C * bytes_per_col,
                          "bytes_per_column": bytes_per_col, "kernel_ms": k_avg_ms,
                          "note": "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / "
                                  "HIP-event duration of the column kernel(s) on the launch stream; PMC traffic: profiles/"},
