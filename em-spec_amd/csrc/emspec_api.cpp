@@ -185,6 +185,8 @@ int emspec_create(const emspec_config* cfg, emspec_engine** out) {
     if (!(cfg->sample_rate > 0) || !(cfg->fmin_hz > 0) || !(cfg->fmax_hz > cfg->fmin_hz) || !(cfg->db_range > 0) ||
         !(cfg->gain > 0) || !(cfg->power_floor >= 0))
         return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "bad sample_rate/fmin/fmax/db_range/gain/power_floor");
+    if (cfg->fmax_hz > 0.5f * cfg->sample_rate)
+        return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "fmax_hz must not exceed sample_rate/2");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, EMSPEC_ERR_NO_DEVICE, "no HIP device available (libemspec has no CPU path)");

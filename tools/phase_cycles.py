@@ -37,3 +37,8 @@ print(f"groups {groups.value}; mean cycles per wave {tot.mean():.0f} (readcyclec
 for i, nm in enumerate(names[:7]):
     v = cyc[:, :, i].astype(np.float64)
     print(f"  {nm:16s} {100 * v.sum() / tot.sum():5.1f} %   per-iteration {v.mean() / ((Cn / (groups.value / S) + 16) / 2):8.0f}")
+if len(sys.argv) > 2:
+    print("per-wave mean cycles per iteration (rows: wave, cols: phases)")
+    it = (Cn / (groups.value / S) + 16) / 2
+    for w in range(waves.value):
+        print(f"  wave {w:2d} " + " ".join(f"{cyc[:, w, i].astype(np.float64).mean() / it:7.0f}" for i in range(7)))
