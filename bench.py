@@ -79,11 +79,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384"])
+    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n1024"])
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--log2-samples", type=int, default=22)
     ap.add_argument("--chunks", type=int, default=4, help="stream-chunks per step (gather overlap, N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reassign", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,8 @@ def main():
     from emspec import shard
     if args.workload == "n16384":
         n, hop = 16384, 512
+    elif args.workload == "n1024":
+        n, hop = 1024, 256
     else:
         n, hop = 4096, 256
     S = args.streams or (1 if args.workload == "single" else 64)
@@ -131,7 +134,7 @@ def main():
         for ci, (a, b) in enumerate(bounds):
             if timed_i is not None and ci == 0:
                 kev[timed_i][0].record(cur)
-            eng.batch_device(pcm[a:b], n, hop, True, db=db[a:b], index=idx[a:b], stream=cur)
+            eng.batch_device(pcm[a:b], n, hop, bool(args.reassign), db=db[a:b], index=idx[a:b], stream=cur)
             if timed_i is not None and ci == nch - 1:
                 kev[timed_i][1].record(cur)
             if world > 1:

@@ -39,7 +39,7 @@ struct emspec_engine {
     mutable std::string err;
     std::map<int, Plan> plans;
     uint8_t* d_lut = nullptr;
-    // batch workspace (generic path histogram; host-API staging)
+    // batch workspace (generic path per-bin records; host-API staging)
     float* d_hist = nullptr;
     size_t hist_bytes = 0;
     char* d_stage = nullptr;
@@ -280,16 +280,23 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
         HIPCHK(e, launch_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
         return EMSPEC_OK;
     }
-    // generic path: global-atomic histogram, then dB/colour
-    const size_t cells = (size_t)S * C * e->cfg.rows;
-    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, cells * sizeof(float)))) return rc;
-    HIPCHK(e, hipMemsetAsync(e->d_hist, 0, cells * sizeof(float), st));
-    FrameSinks sk;
-    sk.hist = e->d_hist;
-    sk.hist_slots = C;
-    sk.total_cols = C;
-    HIPCHK(e, launch_frames(n, pd, pcm, L, S, 0, C, sk, st));
-    HIPCHK(e, launch_finalize(e->d_hist, (int64_t)cells, m, e->d_lut, db, rgba, index, st));
+    // generic path: per-bin records (frames_kernel) -> 32-column LDS tiles (tile_scatter_kernel),
+    // in chunks of streams so the record workspace stays bounded
+    const size_t rec_per_stream = (size_t)C * (n / 2 + 2) * sizeof(uint2);   // frame stride K+1 (even)
+    const size_t budget = (size_t)6 << 30;
+    int chunk = (int)(budget / rec_per_stream);
+    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
+    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, rec_per_stream * chunk))) return rc;
+    const size_t col_cells = (size_t)C * e->cfg.rows;
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int sc = (S - s0 < chunk) ? S - s0 : chunk;
+        FrameSinks sk;
+        sk.records = reinterpret_cast<uint2*>(e->d_hist);
+        HIPCHK(e, launch_frames(n, pd, pcm + (size_t)s0 * L, L, sc, 0, C, sk, st));
+        HIPCHK(e, launch_tile_scatter(sk.records, n, pd, m, e->d_lut, sc, C, db ? db + s0 * col_cells : nullptr,
+                                      rgba ? rgba + 4 * s0 * col_cells : nullptr,
+                                      index ? index + s0 * col_cells : nullptr, st));
+    }
     return EMSPEC_OK;
 }
 

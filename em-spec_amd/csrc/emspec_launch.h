@@ -12,6 +12,9 @@ struct FrameSinks {
     float* power = nullptr;
     int32_t* col = nullptr;
     int32_t* row = nullptr;
+    // compact per-bin records for the tile-scatter kernel: [stream][frame][K] of
+    // (float bits of |X_h|^2, key) with key = (dcol+64)<<16 | row, or 0xFFFFFFFF when dropped
+    uint2* records = nullptr;
     // histogram scatter (global float atomics): hist[stream][slots][rows]
     float* hist = nullptr;
     int64_t hist_slots = 0;    // slots per stream in `hist`
@@ -25,6 +28,11 @@ bool supported_fft(int n);
 // One workgroup per frame: frames [frame0, frame0+nframes) of each of S streams.
 hipError_t launch_frames(int n, const PlanDev& pl, const float* pcm, int64_t L, int S,
                          int64_t frame0, int64_t nframes, const FrameSinks& sinks, hipStream_t st);
+
+// records of all C frames of S streams -> finished columns.  One workgroup per (32-column tile,
+// stream): LDS histogram of the tile, frames [c0-D, c0+tile+D) streamed through it.
+hipError_t launch_tile_scatter(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
+                               int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
 
 // hist cells -> dB / RGBA / palette index (any output may be null). ncells % 4 == 0.
 hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, const uint8_t* lut,

@@ -98,21 +98,28 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     fft_rest<LOG2N, 4>(sm, t, pl.tw);
 
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
-    int wtop = 1;
-    while (wtop * 2 < pl.rows) wtop *= 2;
+    HintLookup lk;
+    lk.init(seb, pl.ebin, pl.rows);
 #pragma unroll 1
     for (int i = 0; i < 9; ++i) {
         const int k = t + T * i;
         if (k > N / 2) break;
         const float2 zm = sm[(k - 1) & (N - 1)], z0 = sm[k], zp = sm[k + 1];
         const float2 wm = sm[(N - k + 1) & (N - 1)], w0 = sm[(N - k) & (N - 1)], wp = sm[N - k - 1];
-        const BinOut o = reassign_bin(pl, seb, wtop, k, zm, z0, zp, wm, w0, wp);
+        const BinOut o = reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
         const int64_t col = jcol + o.dcol;
         if (sk.power) {
             const size_t idx = ((size_t)s * nframes + f) * K + k;
             sk.power[idx] = o.power;
             sk.col[idx] = (int32_t)col;
             sk.row[idx] = o.row;
+        }
+        if (sk.records) {
+            // frame stride is K+1 (even): 16-byte aligned chunks; the pad record is marked dropped
+            const size_t idx = ((size_t)s * nframes + f) * (K + 1) + k;
+            const unsigned key = o.row >= 0 ? ((unsigned)(o.dcol + 64) << 16) | (unsigned)o.row : 0xFFFFFFFFu;
+            sk.records[idx] = make_uint2(__float_as_uint(o.power), key);
+            if (k == N / 2) sk.records[idx + 1] = make_uint2(0u, 0xFFFFFFFFu);
         }
         if (sk.hist && o.row >= 0 && col >= 0 && col < sk.total_cols) {
             const int64_t slot = sk.ring ? (col % sk.hist_slots) : col;
@@ -156,6 +163,111 @@ hipError_t launch_frames(int n, const PlanDev& pl, const float* pcm, int64_t L, 
         case 16384: return launch_frames_t<14>(pl, pcm, L, S, frame0, nframes, sk, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------
+// tile scatter: the "Scatter" and "dB + colour" stages for shapes without a fused kernel.
+// Workgroup (tile, stream) owns columns [c0, c0+TILE): it streams the records of every frame that
+// can reach them through an LDS histogram (exchange-based float accumulate, see lds_accumulate),
+// then writes the finished columns.  Records are read (TILE+2D)/TILE times in total.
+// ---------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(1024) void tile_scatter_kernel(const uint2* __restrict__ rec, int K, int R, int D, int tile,
+                                                            DbMap dm, const uint32_t* __restrict__ lut, int64_t C,
+                                                            float* __restrict__ db, uint32_t* __restrict__ rgba,
+                                                            uint8_t* __restrict__ index) {
+    extern __shared__ float4 smem4[];
+    float* hist = reinterpret_cast<float*>(smem4);              // [tile][R]
+    uint32_t* slut = reinterpret_cast<uint32_t*>(hist + (size_t)tile * R);
+    const int tid = threadIdx.x, s = blockIdx.y;
+    const int64_t c0 = (int64_t)blockIdx.x * tile;
+    const int64_t c1 = (c0 + tile < C) ? c0 + tile : C;
+    for (int q = tid; q < tile * R / 4; q += 1024) reinterpret_cast<float4*>(hist)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) slut[tid] = lut[tid];
+    __syncthreads();
+    const int64_t jlo = c0 - D > 0 ? c0 - D : 0, jhi = (c1 + D < C) ? c1 + D : C;
+    const int span = (int)(c1 - c0);
+    // A job is CH consecutive records of one frame (one thread, 8*CH contiguous bytes).  Lanes of a
+    // wave therefore work CH bins apart, and a thread pre-sums runs of equal (column,row) keys in
+    // registers, so a wide high-frequency row costs one LDS accumulate per thread, not one per bin.
+    const int Kp = K + 1;                           // padded frame stride (even)
+    const int nch = (Kp + CH - 1) / CH;             // chunks per frame
+    const int64_t njobs = (jhi - jlo) * nch;
+    const uint2* base = rec + (size_t)s * C * Kp;
+    for (int64_t job = tid; job < njobs; job += 1024) {
+        const int64_t j = jlo + job / nch;
+        const int k0 = (int)(job % nch) * CH;
+        const uint4* src = reinterpret_cast<const uint4*>(base + (size_t)j * Kp + k0);
+        uint4 q[CH / 2];
+#pragma unroll
+        for (int u = 0; u < CH / 2; ++u) q[u] = (k0 + 2 * u < Kp) ? src[u] : make_uint4(0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu);
+        const int jrel = (int)(j - c0);
+        unsigned cur = 0xFFFFFFFFu;
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const unsigned pbits = (u & 1) ? q[u >> 1].z : q[u >> 1].x;
+            const unsigned key = (u & 1) ? q[u >> 1].w : q[u >> 1].y;
+            const bool flush = key != cur;
+            // flush the finished run (if it was a live one inside this tile)
+            {
+                const int colrel = jrel + (int)(cur >> 16) - 64;
+                const bool ok = flush && (cur != 0xFFFFFFFFu) && ((unsigned)colrel < (unsigned)span);
+                lds_accumulate(hist + (ok ? colrel * R + (int)(cur & 0xFFFFu) : 0), acc, ok);
+            }
+            acc = flush ? __uint_as_float(pbits) : acc + __uint_as_float(pbits);
+            cur = key;
+        }
+        {
+            const int colrel = jrel + (int)(cur >> 16) - 64;
+            const bool ok = (cur != 0xFFFFFFFFu) && ((unsigned)colrel < (unsigned)span);
+            lds_accumulate(hist + (ok ? colrel * R + (int)(cur & 0xFFFFu) : 0), acc, ok);
+        }
+    }
+    __syncthreads();
+    const int ncell4 = span * R / 4;
+    for (int q = tid; q < ncell4; q += 1024) {
+        const float4 e = reinterpret_cast<const float4*>(hist)[q];
+        const float d0 = cell_db(dm, e.x), d1 = cell_db(dm, e.y), d2 = cell_db(dm, e.z), d3 = cell_db(dm, e.w);
+        const int i0 = cell_index(dm, d0), i1 = cell_index(dm, d1), i2 = cell_index(dm, d2), i3 = cell_index(dm, d3);
+        const size_t o = ((size_t)s * C + c0) * R + (size_t)q * 4;
+        if (db) *reinterpret_cast<float4*>(db + o) = make_float4(d0, d1, d2, d3);
+        if (rgba) *reinterpret_cast<uint4*>(rgba + o) = make_uint4(slut[i0], slut[i1], slut[i2], slut[i3]);
+        if (index) *reinterpret_cast<uint32_t*>(index + o) =
+            (uint32_t)i0 | ((uint32_t)i1 << 8) | ((uint32_t)i2 << 16) | ((uint32_t)i3 << 24);
+    }
+}
+
+template <int CH>
+static hipError_t launch_tile_scatter_t(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
+                                        int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
+                                        int tile, size_t lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_scatter_kernel<CH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t ntiles = (C + tile - 1) / tile;
+    hipLaunchKernelGGL(tile_scatter_kernel<CH>, dim3((unsigned)ntiles, (unsigned)S), dim3(1024), lds, st, records,
+                       n / 2 + 1, pl.rows, pl.D, tile, m, reinterpret_cast<const uint32_t*>(lut), C, db,
+                       reinterpret_cast<uint32_t*>(rgba), index);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scatter(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut, int S,
+                               int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st) {
+    if (S <= 0 || C <= 0) return hipSuccess;
+    if (S > 65535) return hipErrorInvalidValue;
+    int tile = (int)((150 * 1024) / ((size_t)pl.rows * 4));
+    tile = tile > 32 ? 32 : tile;
+    if (tile < 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)tile * pl.rows * 4 + 1024;
+    // chunk = consecutive bins per thread: wide enough that adjacent lanes rarely share a row
+    if (n >= 8192) return launch_tile_scatter_t<32>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
+    if (n >= 2048) return launch_tile_scatter_t<8>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
+    return launch_tile_scatter_t<4>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
 }
 
 // ---------------------------------------------------------------------------
