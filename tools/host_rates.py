@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point and latency of the streaming call."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "em-spec_amd")]
+import numpy as np
+import emspec
+from emspec import synth
+
+e = emspec.Engine()
+n, hop = 4096, 256
+pcm = np.repeat(synth.streams(1, 1 << 22), 8, axis=0)
+e.batch(pcm[:1], n, hop, True)
+t0 = time.perf_counter()
+out = e.batch(pcm, n, hop, True, want=("db",))
+dt = time.perf_counter() - t0
+C = out["db"].shape[1]
+print(f"emspec_batch (host buffers, pageable, PCIe in+out): {8 * C / dt:.3e} columns/s "
+      f"({dt * 1e3:.1f} ms for 8 streams x {C} columns; {pcm.nbytes / 1e6:.0f} MB in, {out['db'].nbytes / 1e6:.0f} MB out)")
+e.reset()
+fr = pcm[0]
+for j in range(20):
+    e.column(fr[j * hop:j * hop + n], hop, True)
+t0 = time.perf_counter()
+for j in range(20, 520):
+    e.column(fr[j * hop:j * hop + n], hop, True)
+dt = (time.perf_counter() - t0) / 500
+print(f"emspec_column (streaming, one frame per call: H2D + 2 kernels + D2H + sync): {dt * 1e6:.1f} us per column "
+      f"= {1 / dt:.0f} columns/s per engine (real time needs 187.5/s per stream)")
