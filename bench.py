@@ -82,9 +82,11 @@ def main():
     ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n1024"])
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--log2-samples", type=int, default=22)
-    ap.add_argument("--chunks", type=int, default=4, help="stream-chunks per step (gather overlap, N>1)")
+    ap.add_argument("--chunks", type=int, default=8, help="stream-chunks per step (gather overlap, N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reassign", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (gather via host tensors)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,9 +99,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    if world > 1:
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     import emspec
@@ -112,7 +119,7 @@ def main():
         n, hop = 4096, 256
     S = args.streams or (1 if args.workload == "single" else 64)
     L = 1 << args.log2_samples
-    eng = emspec.Engine(device=local_rank)
+    eng = emspec.Engine(device=dev_index)
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
     first_stream, _ = shard.stream_shard(rank, world, world * S)
@@ -124,8 +131,9 @@ def main():
     bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered = None
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1 and rank == 0:
-        gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=dev) for _ in range(world)] for a, b in bounds]
+        gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=gdev) for _ in range(world)] for a, b in bounds]
 
     cur = torch.cuda.current_stream(dev)
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -142,7 +150,8 @@ def main():
                 ready.record(cur)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(ready)
-                    shard.gather_columns_into(idx[a:b], gathered[ci] if rank == 0 else None, dst=0)
+                    src = idx[a:b] if args.backend == "nccl" else idx[a:b].cpu()   # gloo rehearsal: host tensors
+                    shard.gather_columns_into(src, gathered[ci] if rank == 0 else None, dst=0)
         if world > 1:
             cur.wait_stream(comm_stream)
 
@@ -160,7 +169,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -190,37 +190,6 @@ __device__ __forceinline__ void lds_accumulate(float* cell, float p, bool want) 
     }
 }
 
-// Same, for NB independent (cell, value) pairs per lane: all pending exchanges of a round are
-// issued before any result is consumed, so a lane pays one LDS round trip per round, not per item.
-template <int NB>
-__device__ __forceinline__ void lds_accumulate_n(float* const (&cell)[NB], const float (&p)[NB], const bool (&want)[NB]) {
-    bool todo[NB];
-    bool any = false;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) { todo[i] = want[i]; any = any || want[i]; }
-    while (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-        unsigned old[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            if (todo[i])
-                old[i] = __hip_atomic_exchange(reinterpret_cast<unsigned*>(cell[i]), 0xFFFFFFFFu, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        any = false;
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            if (todo[i]) {
-                if (old[i] != 0xFFFFFFFFu) {
-                    __hip_atomic_store(cell[i], __uint_as_float(old[i]) + p[i], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                    todo[i] = false;
-                } else {
-                    any = true;
-                }
-            }
-        }
-    }
-}
-
 // stage "dB + colour" for one histogram cell
 __device__ __forceinline__ float cell_db(const DbMap& m, float e) {
     return 10.0f * log10f(e * m.scale + 1e-20f);

@@ -13,7 +13,7 @@ struct FrameSinks {
     int32_t* col = nullptr;
     int32_t* row = nullptr;
     // compact per-bin records for the tile-scatter kernel: [stream][frame][K] of
-    // (float bits of |X_h|^2, key) with key = (dcol+64)<<16 | row, or 0xFFFFFFFF when dropped
+    // (float bits of |X_h|^2, key) with key = (dcol+32768)<<16 | row, or 0xFFFFFFFF when dropped
     uint2* records = nullptr;
     // histogram scatter (global float atomics): hist[stream][slots][rows]
     float* hist = nullptr;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         if (sk.records) {
             // frame stride is K+1 (even): 16-byte aligned chunks; the pad record is marked dropped
             const size_t idx = ((size_t)s * nframes + f) * (K + 1) + k;
-            const unsigned key = o.row >= 0 ? ((unsigned)(o.dcol + 64) << 16) | (unsigned)o.row : 0xFFFFFFFFu;
+            const unsigned key = o.row >= 0 ? ((unsigned)(o.dcol + 32768) << 16) | (unsigned)o.row : 0xFFFFFFFFu;
             sk.records[idx] = make_uint2(__float_as_uint(o.power), key);
             if (k == N / 2) sk.records[idx + 1] = make_uint2(0u, 0xFFFFFFFFu);
         }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void tile_scatter_kernel(const uint2* __restr
             const bool flush = key != cur;
             // flush the finished run (if it was a live one inside this tile)
             {
-                const int colrel = jrel + (int)(cur >> 16) - 64;
+                const int colrel = jrel + (int)(cur >> 16) - 32768;
                 const bool ok = flush && (cur != 0xFFFFFFFFu) && ((unsigned)colrel < (unsigned)span);
                 lds_accumulate(hist + (ok ? colrel * R + (int)(cur & 0xFFFFu) : 0), acc, ok);
             }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) void tile_scatter_kernel(const uint2* __restr
             cur = key;
         }
         {
-            const int colrel = jrel + (int)(cur >> 16) - 64;
+            const int colrel = jrel + (int)(cur >> 16) - 32768;
             const bool ok = (cur != 0xFFFFFFFFu) && ((unsigned)colrel < (unsigned)span);
             lds_accumulate(hist + (ok ? colrel * R + (int)(cur & 0xFFFFu) : 0), acc, ok);
         }

@@ -211,3 +211,43 @@ def test_node_addon_on_gpu():
     r = subprocess.run(["node", "test_emspec.js"], cwd=js, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "node addon ok" in r.stdout
+
+
+@pytest.mark.parametrize("rows,n,hop,reassign", [(512, 4096, 256, True), (256, 4096, 256, True), (64, 4096, 256, False),
+                                                  (512, 1024, 256, True), (2048, 2048, 512, True), (1024, 8192, 1000, True),
+                                                  (1024, 1024, 1024, True), (1024, 256, 1, True)])
+def test_other_grids_and_hops(rows, n, hop, reassign):
+    """Row counts other than 1024 (fused ring and tile sizes change), a non-power-of-two hop,
+    hop = N (no overlap), hop = 1, and a non-default frequency range / display mapping."""
+    import emspec
+    frames = 37 if hop >= 64 else 300
+    pcm = synth.streams(2, n + hop * (frames - 1) + min(3, hop - 1))
+    kw = dict(rows=rows, fmin_hz=35.0, fmax_hz=18000.0, gain=3.5, db_range=58.0, gate_db=-65.0)
+    with emspec.Engine(**kw) as e:
+        out = e.batch(pcm, n, hop, reassign, want=("db", "index"))
+        pw, col, row = e.parity_dump(pcm, n, hop, reassign, 0, min(frames, 6))
+    cfg = O.make_cfg(n, hop, reassign, **kw)
+    odb, _, oidx = O.batch_f32(cfg, pcm, want=("db", "index"))
+    assert out["db"].shape == odb.shape == (2, frames, rows)
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    for s in range(2):
+        opw, ocol, orow = O.frames_f32(cfg, pcm[s], 0, min(frames, 6))
+        assert np.array_equal(col[s], ocol) and np.array_equal(row[s], orow) and np.array_equal(pw[s], opw)
+
+
+def test_custom_colormap_and_silence(engine):
+    lut = np.zeros((256, 4), np.uint8)
+    lut[:, 1] = np.arange(256)
+    lut[:, 3] = 255
+    engine.set_colormap(lut)
+    try:
+        n, hop = 4096, 256
+        pcm = synth.streams(1, n + hop * 20)
+        out = engine.batch(pcm, n, hop, True, want=("rgba", "index"))
+        assert np.array_equal(out["rgba"], lut[out["index"]])
+        z = engine.batch(np.zeros((1, n + hop * 5), np.float32), n, hop, True, want=("db", "index"))
+        assert np.all(z["index"] == 0) and np.allclose(z["db"], -200.0, atol=1e-3)      # silence: every bin gated
+    finally:
+        engine.set_colormap(O.default_lut())
