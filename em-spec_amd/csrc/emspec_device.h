@@ -45,6 +45,15 @@ __device__ __forceinline__ float2 cmul_tw(float2 d, float2 w) {
 __device__ __forceinline__ constexpr int padi(int p) { return p + (p >> 4); }
 template <int N> struct PaddedSize { static constexpr int value = N + (N >> 4); };
 
+// Orders this wave's earlier LDS writes before its later LDS reads.  The LDS pipe executes one
+// wave's instructions in order, so nothing is waited for; this only stops the compiler from
+// moving accesses across the point.  Used where a pass reads only what the same wave wrote.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Radix-2 DIF stages S0 .. S0+R-1 of an N = 2^LOG2N point FFT, performed on the
 // 2^R values a thread holds in registers.  Register i is the element with
 // global index  p = hi*2^(B0+R) + i*2^B0 + lo,  B0 = LOG2N-S0-R.
@@ -76,6 +85,35 @@ __device__ __forceinline__ void fft_stages(float2 (&v)[1 << R], int lo, const fl
         }
     }
 }
+
+// The same stages with the twiddle of slot e supplied by w(e); slots are numbered stage by
+// stage: slot = 2^R - 2*mloc + (i mod mloc), mloc = 2^(R-1-u) for local stage u.
+template <int R, class W>
+__device__ __forceinline__ void fft_stages_w(float2 (&v)[1 << R], const W& w) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int mloc = 1 << (R - 1 - u);
+#pragma unroll
+        for (int i = 0; i < (1 << R); ++i) {
+            if (i & mloc) continue;
+            const float2 a = v[i], b = v[i + mloc];
+            v[i] = cadd(a, b);
+            v[i + mloc] = cmul_tw(csub(a, b), w((1 << R) - 2 * mloc + (i & (mloc - 1))));
+        }
+    }
+}
+// twiddle-table index of slot e (radix-16 pass starting at stage S0) for low index lo
+template <int LOG2N, int S0>
+__device__ __forceinline__ int tw_slot_index16(int e, int lo) {
+    constexpr int B0 = LOG2N - S0 - 4;
+    const int u = e < 8 ? 0 : (e < 12 ? 1 : (e < 14 ? 2 : 3));
+    const int mloc = 8 >> u, mm = e - (16 - 2 * mloc);
+    return ((mm << B0) + lo) << (S0 + u);
+}
+struct TwLdsStrided {   // slot e of column lo at base[e*stride]  (base already offset by lo)
+    const float2* base; int stride;
+    __device__ __forceinline__ float2 operator()(int e) const { return base[e * stride]; }
+};
 
 // row = largest r in [0,R) with ebin[r] <= kh ; -1 unless ebin[0] <= kh < ebin[R].
 // Exact float compares against the table: identical to the oracle's binary search.

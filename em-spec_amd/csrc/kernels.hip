@@ -19,10 +19,30 @@ namespace emspec {
 
 // ---------------------------------------------------------------------------
 // FFT passes over the in-place LDS buffer.  16 points per thread, T = N/16.
+// After the first radix-16 pass the transform is 16 independent sub-FFTs of N/16 <= 1024
+// points, and with the index maps below every later pass of a wave touches only positions
+// that the same wave wrote (wave w owns positions [1024w, 1024w+1024)), so those passes are
+// ordered by wave_lds_sync() instead of a workgroup barrier.
 // ---------------------------------------------------------------------------
+// Middle-pass twiddles depend on the low B0 bits of the thread id only: 15 << B0 entries per
+// pass (<= 1020 in total), staged once per workgroup in LDS instead of 15 global loads per
+// thread per pass.
+constexpr int mid_tw_entries(int log2n) {
+    int s0 = 4, n = 0;
+    while (log2n - s0 > 4) { n += 15 << (log2n - s0 - 4); s0 += 4; }
+    return (n + 1) & ~1;   // keep the next region 16-byte aligned
+}
 template <int LOG2N, int S0>
-__device__ __forceinline__ void fft_rest(float2* sm, int t, const float2* __restrict__ tw) {
-    constexpr int N = 1 << LOG2N, T = N / 16;
+__device__ __forceinline__ void stage_mid_twiddles(float2* stw, const float2* __restrict__ tw, int t, int nthreads) {
+    if constexpr (LOG2N - S0 > 4) {
+        constexpr int B0 = LOG2N - S0 - 4, NE = 15 << B0;
+        for (int x = t; x < NE; x += nthreads) stw[x] = tw[tw_slot_index16<LOG2N, S0>(x >> B0, x & ((1 << B0) - 1))];
+        stage_mid_twiddles<LOG2N, S0 + 4>(stw + NE, tw, t, nthreads);
+    }
+}
+
+template <int LOG2N, int S0>
+__device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, const float2* __restrict__ tw) {
     constexpr int REM = LOG2N - S0;
     if constexpr (REM > 4) {
         // middle pass: stages S0..S0+3, one group of 16 per thread, in place
@@ -32,19 +52,20 @@ __device__ __forceinline__ void fft_rest(float2* sm, int t, const float2* __rest
         float2 v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = sm[padi(base + (i << B0))];
-        fft_stages<LOG2N, S0, 4>(v, lo, tw);
+        fft_stages_w<4>(v, TwLdsStrided{stw + lo, 1 << B0});
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm[padi(base + (i << B0))] = v[i];
-        __syncthreads();
-        fft_rest<LOG2N, S0 + 4>(sm, t, tw);
+        wave_lds_sync();
+        fft_rest<LOG2N, S0 + 4>(sm, stw + (15 << B0), t, tw);
     } else {
-        // last pass: stages S0..LOG2N-1 (R = REM <= 4), G groups per thread;
-        // output rewritten in natural frequency order (unpadded) after a barrier.
+        // last pass: stages S0..LOG2N-1 (R = REM <= 4), G consecutive groups per thread
+        // (positions 16t .. 16t+15: wave-local); output rewritten in natural frequency
+        // order (unpadded) after a barrier.
         constexpr int R = REM, G = 16 >> R;
         float2 v[G][1 << R];
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const int g = t + T * gi;
+            const int g = G * t + gi;
 #pragma unroll
             for (int i = 0; i < (1 << R); ++i) v[gi][i] = sm[padi((g << R) + i)];
             fft_stages<LOG2N, S0, R>(v[gi], 0, tw);
@@ -52,7 +73,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, int t, const float2* __rest
         __syncthreads();
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const int g = t + T * gi;
+            const int g = G * t + gi;
 #pragma unroll
             for (int i = 0; i < (1 << R); ++i) {
                 const unsigned p = (unsigned)((g << R) + i);
@@ -71,7 +92,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     constexpr int N = 1 << LOG2N, T = N / 16, K = N / 2 + 1;
     extern __shared__ float4 smem4[];
     float2* sm = reinterpret_cast<float2*>(smem4);
-    float* seb = reinterpret_cast<float*>(sm + PaddedSize<N>::value);
+    float2* stw = sm + PaddedSize<N>::value;                       // middle-pass twiddles
+    float* seb = reinterpret_cast<float*>(stw + mid_tw_entries(LOG2N));
     const int t = threadIdx.x;
     const int64_t f = blockIdx.x;          // frame within the launch
     const int s = blockIdx.y;              // stream
@@ -79,6 +101,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     const int64_t jcol = j + sk.col_offset; // its own absolute column
 
     for (int r = t; r <= pl.rows; r += T) seb[r] = pl.ebin[r];
+    stage_mid_twiddles<LOG2N, 4>(stw, pl.tw, t, T);
 
     // stage "Frame gather" + packing z = x + j*ramp*x, ramp = (n-N/2)*(2/N) exact
     const float* x = pcm + (size_t)s * L + j * pl.hop;
@@ -95,7 +118,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) sm[padi(t + T * i)] = v[i];
     __syncthreads();
-    fft_rest<LOG2N, 4>(sm, t, pl.tw);
+    fft_rest<LOG2N, 4>(sm, stw, t, pl.tw);
 
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
     HintLookup lk;
@@ -134,7 +157,7 @@ template <int LOG2N>
 static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
                                   int64_t nframes, const FrameSinks& sk, hipStream_t st) {
     constexpr int N = 1 << LOG2N;
-    const size_t lds = (size_t)PaddedSize<N>::value * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
+    const size_t lds = (size_t)(PaddedSize<N>::value + mid_tw_entries(LOG2N)) * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
