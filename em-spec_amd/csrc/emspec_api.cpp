@@ -6,6 +6,7 @@
 // There is deliberately NO CPU path here: without a gfx950 device
 // emspec_create fails.
 #include "../../include/emspec.h"
+#include "../../include/emspec_debug.h"
 #include "emspec_launch.h"
 
 #include <cmath>

@@ -1,0 +1,31 @@
+/*
+ * emspec_debug.h — diagnostic entry points of libemspec.  NOT part of the drop-in
+ * boundary: nothing on the product path calls them.  They exist so that tests and
+ * tools can (a) compare the kernels' two row-lookup implementations on arbitrary
+ * inputs and (b) read per-phase cycle counts from the stamped (diagnostic) build of
+ * the fused kernel.  [BUILD-DEFINED]; the reference has no counterpart.
+ */
+#ifndef EMSPEC_DEBUG_H
+#define EMSPEC_DEBUG_H
+#include "emspec.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Evaluate the hinted row lookup (fused/generic kernels) and the binary search on `count`
+ * host values of k-hat for fft size n: out_hint[i], out_exact[i] = row or -1. */
+int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_t count,
+                            int32_t* out_hint, int32_t* out_exact);
+
+/* Run the stamped build of the fused kernel on device-resident pcm and return, per
+ * workgroup and wave, the shader-clock cycles spent in each barrier-delimited phase:
+ * cycles[groups][waves][8] (host).  Call with cycles == NULL to get *groups / *waves. */
+int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S, int64_t L,
+                              int32_t n, int32_t hop, int32_t reassign, float* db_dev,
+                              uint8_t* index_dev, uint64_t* cycles, int64_t* groups,
+                              int32_t* waves);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

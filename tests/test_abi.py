@@ -16,9 +16,13 @@ HAS_GPU = torch.cuda.is_available()
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "emspec.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(emspec_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if h.endswith(".h"):
+            src = open(os.path.join(ROOT, "include", h)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(emspec_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_symbols_exported():
@@ -28,6 +32,7 @@ def test_header_symbols_exported():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/emspec.h but not exported by libemspec.so"
     assert set(emspec.SYMBOLS) <= set(names)
+    assert "emspec_debug_row_lookup" in names and "emspec_debug_phase_cycles" in names
 
 
 def test_library_has_gfx950_code_object():
