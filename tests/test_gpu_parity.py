@@ -251,3 +251,46 @@ def test_custom_colormap_and_silence(engine):
         assert np.all(z["index"] == 0) and np.allclose(z["db"], -200.0, atol=1e-3)      # silence: every bin gated
     finally:
         engine.set_colormap(O.default_lut())
+
+
+def test_full_batch_spot_checks_against_oracle(engine):
+    """BASELINE config 3 at full size (64 streams x 2^22 samples, 1,047,616 columns): random
+    (stream, column) cells of the full run are checked against the oracle evaluated on the local
+    slice of audio that can reach them (column c depends on frames c-8 .. c+8 only), including
+    segment boundaries of the fused kernel and the first/last columns of a stream."""
+    import torch
+    n, hop, D = 4096, 256, 8
+    S, L = 64, 1 << 22
+    base = synth.streams(4, L)
+    rng = np.random.default_rng(99)
+    pcm = np.stack([np.roll(base[s % 4], 1237 * s) * (0.5 + 0.5 * ((s * 7) % 5) / 4) for s in range(S)]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pcm).to(dev)
+    Cn = (L - n) // hop + 1
+    db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, Cn, 1024), dtype=torch.uint8, device=dev)
+    engine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    cfg = O.make_cfg(n, hop, True)
+    cols = [0, 1, 7, 8, 9, Cn - 1, Cn - 2, Cn - 9, 1023, 1024, 1025, 511, 512] + list(rng.integers(20, Cn - 20, 12))
+    worst = 0.0
+    for c in cols:
+        s = int(rng.integers(0, S))
+        f0 = max(0, c - D)
+        f1 = min(Cn - 1, c + D)
+        seg = pcm[s, f0 * hop:f1 * hop + n]
+        odb, _, oidx = O.batch_f32(cfg, seg[None], want=("db", "index"), threads=1)
+        got = db[s, c].cpu().numpy()
+        ref = odb[0, c - f0]
+        worst = max(worst, float(np.max(np.abs(got - ref))))
+        d = np.abs(idx[s, c].cpu().numpy().astype(int) - oidx[0, c - f0].astype(int))
+        assert d.max() <= 1
+    assert worst < 8.7e-4, worst
+    # identical streams give identical columns (no cross-stream leakage in the batch)
+    xb = x.clone()
+    xb[5] = x[9]
+    db2 = torch.empty((S, 256, 1024), dtype=torch.float32, device=dev)
+    engine.batch_device(xb[:, :n + hop * 255].contiguous(), n, hop, True, db=db2)
+    torch.cuda.synchronize()
+    # (float sums are order-dependent in the last bits, so equal streams agree to ~1e-5 dB, not bitwise)
+    assert float(torch.max(torch.abs(db2[5] - db2[9]))) < 2e-4
