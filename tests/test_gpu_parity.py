@@ -294,3 +294,18 @@ def test_full_batch_spot_checks_against_oracle(engine):
     torch.cuda.synchronize()
     # (float sums are order-dependent in the last bits, so equal streams agree to ~1e-5 dB, not bitwise)
     assert float(torch.max(torch.abs(db2[5] - db2[9]))) < 2e-4
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a plain C ABI: build a C program against include/emspec.h + libemspec.so and run it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_driver")
+    lib = os.path.join(root, "em-spec_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", os.path.join(root, "tests", "cdriver", "abi_driver.c"),
+                           "-I", os.path.join(root, "include"), "-L", lib, "-lemspec", "-lm",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi_driver ok" in r.stdout
