@@ -211,6 +211,18 @@ def main():
                          "note": "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / "
                                  "HIP-event duration of the column kernel(s) on the launch stream; PMC traffic: profiles/"},
         }
+        if world == 1 and args.workload == "batch64":
+            # BASELINE configs[1] (one stream of 2^22 samples) measured beside the headline, same engine
+            one = pcm[:1].contiguous()
+            for _ in range(3):
+                eng.batch_device(one, n, hop, True, db=db[:1], index=idx[:1], stream=cur)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            reps = 50
+            for _ in range(reps):
+                eng.batch_device(one, n, hop, True, db=db[:1], index=idx[:1], stream=cur)
+            torch.cuda.synchronize(dev)
+            line["config"]["single_stream_columns_per_s"] = C * reps / (time.perf_counter() - t1)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, hop)
         else:
