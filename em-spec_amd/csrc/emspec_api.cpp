@@ -39,6 +39,7 @@ struct emspec_engine {
     std::string arch;
     mutable std::string err;
     std::map<int, Plan> plans;
+    std::vector<float> custom_edges_hz;   // rows+1 entries when emspec_set_row_edges_hz was called
     uint8_t* d_lut = nullptr;
     // batch workspace (generic path per-bin records; host-API staging)
     float* d_hist = nullptr;
@@ -112,8 +113,10 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
     p.h_ebin.resize(R + 1);
     const double ratio = (double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz;
     for (int r = 0; r <= R; ++r)
-        p.h_ebin[r] = (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n /
-                              (double)e->cfg.sample_rate);
+        p.h_ebin[r] = e->custom_edges_hz.empty()
+                          ? (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n /
+                                    (double)e->cfg.sample_rate)
+                          : (float)((double)e->custom_edges_hz[r] * (double)n / (double)e->cfg.sample_rate);
     for (int r = 0; r < R; ++r)
         if (!(p.h_ebin[r] < p.h_ebin[r + 1])) return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges are not strictly increasing in float32 (too many rows for this range)");
     HIPCHK(e, hipMalloc(&p.d_tw, sizeof(float) * n));
@@ -130,6 +133,7 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     d.tw = p.d_tw;
     d.ebin = p.d_ebin;
     d.rows = e->cfg.rows;
+    d.log_rows = e->custom_edges_hz.empty() ? 1 : 0;
     d.D = latency(p.n, hop, reassign);
     d.reassign = reassign ? 1 : 0;
     d.hop = hop;
@@ -158,6 +162,8 @@ int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
 }
 
 }  // namespace
+
+static void drop_plans(emspec_engine* e);
 
 extern "C" {
 
@@ -219,7 +225,7 @@ void emspec_destroy(emspec_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (auto& kv : e->plans) { (void)hipFree(kv.second.d_tw); (void)hipFree(kv.second.d_ebin); }
+    drop_plans(e);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -230,6 +236,43 @@ const char* emspec_last_error(const emspec_engine* e) { return e ? e->err.c_str(
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign) {
     return e && fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
+}
+
+static void drop_plans(emspec_engine* e) {
+    for (auto& kv : e->plans) { (void)hipFree(kv.second.d_tw); (void)hipFree(kv.second.d_ebin); }
+    e->plans.clear();
+}
+
+int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    if (e->st_reassign >= 0 && e->st_fed > e->st_emitted) return fail(e, EMSPEC_ERR_STATE, "columns are pending; flush or reset before changing the row edges");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (!edges_hz) {   // back to the configured log axis
+        e->custom_edges_hz.clear();
+        drop_plans(e);
+        return EMSPEC_OK;
+    }
+    if (count != e->cfg.rows + 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "need rows+1 edges");
+    for (int r = 0; r <= e->cfg.rows; ++r) {
+        const float f = edges_hz[r];
+        if (!(f > 0.0f) || !(f <= 0.5f * e->cfg.sample_rate) || (r > 0 && !(f > edges_hz[r - 1])))
+            return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges must be strictly increasing in (0, sample_rate/2]");
+    }
+    e->custom_edges_hz.assign(edges_hz, edges_hz + count);
+    drop_plans(e);
+    return EMSPEC_OK;
+}
+
+int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count) {
+    if (!e || !edges_hz) return EMSPEC_ERR_INVALID_ARG;
+    if (count != e->cfg.rows + 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "need room for rows+1 edges");
+    const int R = e->cfg.rows;
+    const double ratio = (double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz;
+    for (int r = 0; r <= R; ++r)
+        edges_hz[r] = e->custom_edges_hz.empty() ? (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R))
+                                                 : e->custom_edges_hz[r];
+    return EMSPEC_OK;
 }
 
 int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba) {

@@ -17,6 +17,7 @@ struct PlanDev {
     const float2* tw;    // twiddle table, N/2 entries: (cos, -sin)(2*pi*q/N); tw[N/4] == (0,-1) exactly
     const float* ebin;   // row edges in DFT-bin units, rows+1 entries, strictly increasing
     int rows;            // R
+    int log_rows;        // 1: edges are log-spaced (hinted lookup is valid); 0: arbitrary monotone table (binary search)
     int D;               // max |column shift| = ceil(N/(2*hop)) (0 when reassign is off)
     int reassign;        // 0/1
     int hop;
@@ -133,15 +134,25 @@ __device__ __forceinline__ int row_lookup(const float* eb, int R, int wtop, floa
 // against the table decide.  Verified around every edge by tests/test_gpu_parity.py
 // (emspec_debug_row_lookup).  Garbage / NaN inputs map to row -1 through the range test.
 struct HintLookup {
-    const float* eb; int R; float e0, eR, l2e0, rscale;
-    __device__ __forceinline__ void init(const float* table, const float* gtable, int rows) {
+    const float* eb; int R; float e0, eR, l2e0, rscale; int wtop;   // wtop > 0: table is not log-spaced, search it
+    __device__ __forceinline__ void init(const float* table, const float* gtable, int rows, int log_rows = 1) {
         eb = table; R = rows; e0 = gtable[0]; eR = gtable[rows];
         l2e0 = log2f(e0);
         rscale = (float)rows / (log2f(eR) - l2e0);
+        wtop = 0;
+        if (!log_rows) { wtop = 1; while (wtop * 2 < rows) wtop *= 2; }
     }
     __device__ __forceinline__ bool in_range(float kh) const { return (kh >= e0) && (kh < eR); }
     // row for an in-range kh (any kh is safe: the hint is clamped into the table)
     __device__ __forceinline__ int row_unchecked(float kh) const {
+        if (wtop) {   // wave-uniform: arbitrary monotone edges (emspec_set_row_edges_hz)
+            int lo = 0;
+            for (int w = wtop; w > 0; w >>= 1) {
+                const int mid = lo + w;
+                if (mid < R && eb[mid] <= kh) lo = mid;
+            }
+            return lo;
+        }
         int r0 = (int)((__log2f(kh) - l2e0) * rscale);
         r0 = max(0, min(r0, R - 1));
         const float lo = eb[r0], hi = eb[r0 + 1];

@@ -122,7 +122,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
 
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
     HintLookup lk;
-    lk.init(seb, pl.ebin, pl.rows);
+    lk.init(seb, pl.ebin, pl.rows, pl.log_rows);
 #pragma unroll 1
     for (int i = 0; i < 9; ++i) {
         const int k = t + T * i;
@@ -334,7 +334,7 @@ __global__ void row_lookup_probe_kernel(const float* __restrict__ ebin, int rows
     for (int r = threadIdx.x; r <= rows; r += blockDim.x) seb[r] = ebin[r];
     __syncthreads();
     HintLookup lk;
-    lk.init(seb, ebin, rows);
+    lk.init(seb, ebin, rows, 1);
     int wtop = 1;
     while (wtop * 2 < rows) wtop *= 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {

@@ -22,7 +22,8 @@ SYMBOLS = [
     "emspec_default_config", "emspec_create", "emspec_destroy", "emspec_last_error", "emspec_set_colormap",
     "emspec_num_columns", "emspec_latency_columns", "emspec_column", "emspec_column_flush", "emspec_reset",
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
-    "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused",
+    "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
+    "emspec_get_row_edges_hz",
 ]
 
 
@@ -77,6 +78,8 @@ def load():
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emspec_parity_dump_device.argtypes = lib.emspec_parity_dump.argtypes + [C.c_void_p]
     lib.emspec_uses_fused.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.emspec_set_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.emspec_get_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
@@ -149,6 +152,19 @@ class Engine:
         lut = np.ascontiguousarray(lut, np.uint8)
         assert lut.shape == (256, 4)
         self._chk(self._lib.emspec_set_colormap(self._h, _np_ptr(lut)))
+
+    def set_row_edges_hz(self, edges_hz):
+        """rows+1 strictly increasing edges in Hz, or None for the configured log axis."""
+        if edges_hz is None:
+            self._chk(self._lib.emspec_set_row_edges_hz(self._h, None, 0))
+        else:
+            edges_hz = np.ascontiguousarray(edges_hz, np.float32)
+            self._chk(self._lib.emspec_set_row_edges_hz(self._h, _np_ptr(edges_hz), edges_hz.size))
+
+    def row_edges_hz(self):
+        out = np.empty(self.rows + 1, np.float32)
+        self._chk(self._lib.emspec_get_row_edges_hz(self._h, _np_ptr(out), out.size))
+        return out
 
     def tables(self, n):
         eb = np.empty(self.rows + 1, np.float32)

@@ -242,6 +242,28 @@ static napi_value SetColormap(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* setRowEdges(handle, Float32Array(rows+1) | null) ; getRowEdges(handle, Float32Array(rows+1)) */
+static napi_value SetRowEdges(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* p = NULL; size_t len = 0;
+    if (argc < 2 || !get_typed(env, argv[1], napi_float32_array, &p, &len, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "edges must be a Float32Array(rows+1) or null"); return NULL; }
+    int rc = emspec_set_row_edges_hz(h->e, (const float*)p, (int32_t)len);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+static napi_value GetRowEdges(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* p = NULL; size_t len = 0;
+    if (argc < 2 || !get_typed(env, argv[1], napi_float32_array, &p, &len, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "out must be a Float32Array(rows+1)"); return NULL; }
+    int rc = emspec_get_row_edges_hz(h->e, (float*)p, (int32_t)len);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
 static napi_value NumColumns(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -276,6 +298,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
+        {"setRowEdges", NULL, SetRowEdges, NULL, NULL, NULL, napi_default, NULL},
+        {"getRowEdges", NULL, GetRowEdges, NULL, NULL, NULL, napi_default, NULL},
         {"numColumns", NULL, NumColumns, NULL, NULL, NULL, napi_default, NULL},
         {"latencyColumns", NULL, LatencyColumns, NULL, NULL, NULL, napi_default, NULL},
     };

@@ -50,8 +50,45 @@ class Engine {
   }
 
   setColormap(rgba256) { native.setColormap(this._h, rgba256); }
+
+  /** Install any strictly increasing frequency axis: Float32Array(rows+1) of edges in Hz; null = log axis. */
+  setRowEdges(edgesHz) { native.setRowEdges(this._h, edgesHz); }
+  /** The axis in use (rows+1 edges in Hz): the inverse map for the shift+hover frequency read-out. */
+  getRowEdges() { const e = new Float32Array(this.rows + 1); native.getRowEdges(this._h, e); return e; }
+  /** Frequency (Hz) at fractional row y, geometric within the row. */
+  rowToHz(y) {
+    const e = this.getRowEdges();
+    const r = Math.min(this.rows - 1, Math.max(0, Math.floor(y)));
+    return e[r] * Math.pow(e[r + 1] / e[r], Math.min(1, Math.max(0, y - r)));
+  }
   reset() { native.reset(this._h); }
   destroy() { if (this._h) { native.destroy(this._h); this._h = null; } }
+}
+
+/**
+ * One [BUILD-DEFINED] law for the reference's "Frequency Scale" (zoom) and "Low-End Boost"
+ * sliders (their real laws are undocumented): the axis spans fmin .. fmin*(fmax/fmin)^(1/freqScale)
+ * and row r sits at u = (r/rows)^lowEndBoost along the log range, so lowEndBoost > 1 gives the
+ * low end more rows.  Returns Float32Array(rows+1) for Engine#setRowEdges.
+ */
+function warpedEdges(rows, fminHz, fmaxHz, lowEndBoost = 1, freqScale = 1) {
+  const e = new Float32Array(rows + 1);
+  const span = Math.log(fmaxHz / fminHz) / freqScale;
+  for (let r = 0; r <= rows; r++) e[r] = fminHz * Math.exp(span * Math.pow(r / rows, lowEndBoost));
+  return e;
+}
+
+/** The reference's colour ramp (5-stop gradient measured from its screenshot) with a brightness factor: Uint8Array(1024). */
+function makeColormap(brightness = 0.5, stops = [[0, 0, 0], [80, 0, 80], [200, 50, 50], [255, 150, 0], [255, 255, 200]]) {
+  const lut = new Uint8Array(1024);
+  const n = stops.length - 1;
+  for (let i = 0; i < 256; i++) {
+    const v = Math.min(1, (i / 255) * (brightness / 0.5));
+    const t = v * n, s = Math.min(n - 1, Math.floor(t)), f = t - s;
+    for (let c = 0; c < 3; c++) lut[4 * i + c] = Math.round(stops[s][c] + f * (stops[s + 1][c] - stops[s][c]));
+    lut[4 * i + 3] = 255;
+  }
+  return lut;
 }
 
 let defaultEngine = null;
@@ -66,6 +103,8 @@ module.exports = {
   Engine,
   createEngine: (config) => new Engine(config),
   computeSpectrogramColumn,
+  warpedEdges,
+  makeColormap,
   numColumns: native.numColumns,
   latencyColumns: native.latencyColumns,
 };

@@ -97,6 +97,19 @@ const char* emspec_last_error(const emspec_engine* e);
  * is the 5-stop gradient measured from assets/settings.png. */
 int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba256x4);
 
+/*
+ * Frequency axis.  By default the R rows are log-spaced between fmin_hz and fmax_hz.
+ * emspec_set_row_edges_hz installs any strictly increasing table of rows+1 edges in
+ * (0, sample_rate/2] instead — the hook for the reference's "Frequency Scale" (zoom) and
+ * "Low-End Boost" sliders (README.md:48-49), whose laws are undocumented and therefore
+ * left to the host (em-spec_amd/js/index.js ships one).  NULL restores the log axis.
+ * Row r collects the bins whose reassigned frequency lies in [edge[r], edge[r+1]).
+ * emspec_get_row_edges_hz returns the table in use: the inverse map the shift+hover
+ * frequency read-out needs (README.md:39).  Not allowed while streaming columns are pending.
+ */
+int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count);
+int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count);
+
 /* Number of columns a stream of L samples yields: (L-n)/hop+1, or 0. */
 int64_t emspec_num_columns(int64_t L, int32_t n, int32_t hop);
 

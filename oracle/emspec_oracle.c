@@ -42,8 +42,25 @@ static void make_twiddle(int n, float* tw) {
     tw[2 * (n / 4)] = 0.0f;
     tw[2 * (n / 4) + 1] = -1.0f;
 }
+/* Optional arbitrary monotone axis (mirrors emspec_set_row_edges_hz): rows+1 edges in Hz. */
+static float* g_custom_edges = NULL;
+static int g_custom_count = 0;
+int eo_set_custom_edges_hz(const float* hz, int count) {
+    free(g_custom_edges); g_custom_edges = NULL; g_custom_count = 0;
+    if (hz && count > 0) {
+        g_custom_edges = (float*)malloc(sizeof(float) * count);
+        memcpy(g_custom_edges, hz, sizeof(float) * count);
+        g_custom_count = count;
+    }
+    return 0;
+}
+
 static void make_edges64(const eo_cfg* c, double* e) {
-    /* log-spaced row edges, expressed in DFT-bin units (Hz * N / fs) */
+    /* row edges expressed in DFT-bin units (Hz * N / fs): custom table, or log-spaced */
+    if (g_custom_edges && g_custom_count == c->rows + 1) {
+        for (int r = 0; r <= c->rows; ++r) e[r] = (double)g_custom_edges[r] * (double)c->n / (double)c->sample_rate;
+        return;
+    }
     double ratio = (double)c->fmax_hz / (double)c->fmin_hz;
     for (int r = 0; r <= c->rows; ++r)
         e[r] = (double)c->fmin_hz * pow(ratio, (double)r / (double)c->rows) *

@@ -41,6 +41,8 @@ typedef struct eo_cfg {
 /* twiddle: n floats (n/2 complex, re/im interleaved); ebin: rows+1 floats. */
 int eo_tables(const eo_cfg* c, float* twiddle, float* ebin);
 int eo_default_lut(uint8_t* rgba256x4);
+/* process-wide: use this Hz edge table (rows+1 entries) instead of the log axis; NULL resets */
+int eo_set_custom_edges_hz(const float* hz, int count);
 
 /* One stream, frames [frame0, frame0+nframes): per-bin outputs [nframes][n/2+1]. */
 int eo_frames_f32(const eo_cfg* c, const float* pcm, int64_t L, int64_t frame0,

@@ -67,6 +67,14 @@ def tables(cfg):
     return tw, eb
 
 
+def set_custom_edges_hz(hz):
+    if hz is None:
+        lib().eo_set_custom_edges_hz(None, 0)
+    else:
+        hz = np.ascontiguousarray(hz, np.float32)
+        lib().eo_set_custom_edges_hz(_p(hz, C.c_float), C.c_int(hz.size))
+
+
 def default_lut():
     lut = np.empty((256, 4), np.uint8)
     lib().eo_default_lut(_p(lut, C.c_uint8))

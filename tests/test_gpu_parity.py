@@ -309,3 +309,37 @@ def test_c_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "abi_driver ok" in r.stdout
+
+
+@pytest.mark.parametrize("n,hop", [(4096, 256), (1024, 256)])
+def test_custom_row_edges(n, hop):
+    """An arbitrary monotone frequency axis (the hook for 'Low-End Boost' / 'Frequency Scale'):
+    the kernels switch to the binary-search row lookup; results must still match the oracle exactly."""
+    import emspec
+    rows = 512
+    u = np.arange(rows + 1) / rows
+    edges = (30.0 * np.exp(np.log(16000.0 / 30.0) * u ** 1.9)).astype(np.float32)       # warped (low end boosted)
+    edges[200:260] = np.linspace(edges[200], edges[260], 61)[:60].astype(np.float32)   # a linear stretch: not log-spaced
+    frames = 30
+    pcm = synth.streams(2, n + hop * (frames - 1))
+    with emspec.Engine(rows=rows) as e:
+        e.set_row_edges_hz(edges)
+        assert np.array_equal(e.row_edges_hz(), edges)
+        out = e.batch(pcm, n, hop, True, want=("db",))
+        pw, col, row = e.parity_dump(pcm, n, hop, True, 0, 6)
+        with pytest.raises(emspec.EmspecError):
+            e.set_row_edges_hz(edges[::-1].copy())
+        e.set_row_edges_hz(None)
+        back = e.batch(pcm, n, hop, True, want=("db",))
+    O.set_custom_edges_hz(edges)
+    try:
+        cfg = O.make_cfg(n, hop, True, rows=rows)
+        odb, _, _ = O.batch_f32(cfg, pcm, want=("db",))
+        for s in range(2):
+            opw, ocol, orow = O.frames_f32(cfg, pcm[s], 0, 6)
+            assert np.array_equal(row[s], orow) and np.array_equal(col[s], ocol)
+    finally:
+        O.set_custom_edges_hz(None)
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    odb_log, _, _ = O.batch_f32(O.make_cfg(n, hop, True, rows=rows), pcm, want=("db",))
+    assert np.max(np.abs(back["db"] - odb_log)) < 8.7e-4
