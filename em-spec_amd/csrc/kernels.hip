@@ -159,7 +159,10 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     constexpr int N = 1 << LOG2N;
     const size_t lds = (size_t)(PaddedSize<N>::value + mid_tw_entries(LOG2N)) * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static bool attr_done[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_done[dev_ & 63];   // the attribute is per device
     if (lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_kernel<LOG2N>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -265,7 +268,10 @@ template <int CH>
 static hipError_t launch_tile_scatter_t(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                                         int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
                                         int tile, size_t lds) {
-    static bool attr_set = false;
+    static bool attr_done[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_done[dev_ & 63];   // the attribute is per device
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_scatter_kernel<CH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
