@@ -27,8 +27,10 @@ for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     if not f:
         continue
     vals = {}
-    for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] == name and "emspec" in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == name and "emspec" in r["Kernel_Name"]]
+    big = max(int(r["Grid_Size"]) for r in rows)      # the timed batch launches (bench.py also times one-stream launches)
+    for r in rows:
+        if int(r["Grid_Size"]) == big:
             vals.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
     out[name] = {k: {"per_launch_KiB": v, "mean_KiB": sum(v) / len(v)} for k, v in vals.items()}
 if out:
