@@ -344,6 +344,14 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     return EMSPEC_OK;
 }
 
+// Diagnostic: non-zero if a bounded spin of the decoupled-team fused kernel ever timed out on this device.
+int emspec_debug_fused_error(emspec_engine* e) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return EMSPEC_ERR_HIP;
+    (void)hipDeviceSynchronize();
+    return fused_read_errflag();
+}
+
 // Diagnostic (tests only): evaluate the fused kernels' hinted row lookup and the generic
 // binary search on `count` host values of k-hat for fft size n.
 int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_t count, int32_t* out_hint,

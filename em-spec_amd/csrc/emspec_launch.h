@@ -46,6 +46,7 @@ hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t*
                         unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
 bool fused_supported(int n, int hop, int rows, int reassign);
 int fused_waves_per_group();
+int fused_read_errflag();   // non-zero if a bounded spin of the decoupled-team kernel ever timed out
 hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh, int64_t count, int32_t* out_hint,
                                    int32_t* out_exact, hipStream_t st);
 

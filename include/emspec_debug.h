@@ -25,6 +25,10 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
                               uint8_t* index_dev, uint64_t* cycles, int64_t* groups,
                               int32_t* waves);
 
+/* Synchronises the device and returns non-zero if a bounded spin of the decoupled-team fused
+ * kernel (EMSPEC_FUSED_VARIANT=r8t) ever timed out: a protocol bug, results are then invalid. */
+int emspec_debug_fused_error(emspec_engine* e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,3 +343,12 @@ def test_custom_row_edges(n, hop):
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
     odb_log, _, _ = O.batch_f32(O.make_cfg(n, hop, True, rows=rows), pcm, want=("db",))
     assert np.max(np.abs(back["db"] - odb_log)) < 8.7e-4
+
+
+def test_no_spin_timeouts(engine):
+    """The decoupled-team fused kernel bounds every wait; a timeout (protocol bug) raises a device flag."""
+    import ctypes as C
+    import emspec
+    lib = emspec.load()
+    lib.emspec_debug_fused_error.argtypes = [C.c_void_p]
+    assert lib.emspec_debug_fused_error(engine._h) == 0
