@@ -231,6 +231,94 @@ static napi_value Batch(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* batchAsync(handle, pcm, S, L, fftSize, hop, reassign, outDb?, outRgba?, outIndex?) -> Promise<columns>
+ * Same as batch() but the work runs on the libuv thread pool (napi_create_async_work), so the
+ * renderer's JS thread is not blocked for the duration of a large batch.  The typed arrays are
+ * kept alive by references until completion; the caller must not touch them, nor call into the
+ * same engine, before the promise settles (an engine is not thread-safe). */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[4];
+    emspec_engine* e;
+    const float* pcm;
+    emspec_out out;
+    int32_t S, n, hop, reassign;
+    int64_t L, C;
+    int rc;
+    char msg[256];
+} batch_job;
+
+static void batch_execute(napi_env env, void* data) {
+    (void)env;
+    batch_job* j = (batch_job*)data;
+    j->rc = emspec_batch(j->e, j->pcm, j->S, j->L, j->n, j->hop, j->reassign, &j->out);
+    if (j->rc != EMSPEC_OK) { strncpy(j->msg, emspec_last_error(j->e), sizeof(j->msg) - 1); j->msg[sizeof(j->msg) - 1] = 0; }
+}
+
+static void batch_complete(napi_env env, napi_status status, void* data) {
+    batch_job* j = (batch_job*)data;
+    for (int i = 0; i < 4; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    if (status == napi_ok && j->rc == EMSPEC_OK) {
+        napi_value v; napi_create_int64(env, j->C, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value code, msg, err;
+        napi_create_string_utf8(env, status == napi_ok ? status_name(j->rc) : "EMSPEC_NAPI", NAPI_AUTO_LENGTH, &code);
+        napi_create_string_utf8(env, status == napi_ok ? j->msg : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, code, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j);
+}
+
+static napi_value BatchAsync(napi_env env, napi_callback_info info) {
+    size_t argc = 10; napi_value argv[10];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 8) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "batchAsync(handle, pcm, S, L, fftSize, hop, reassign, outDb[, outRgba, outIndex])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* pcm; size_t plen;
+    if (!get_typed(env, argv[1], napi_float32_array, &pcm, &plen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; int64_t L; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[3], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[6], &argv[6]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[6], &reassign));
+    if (S < 1 || L < 1 || (size_t)S * (size_t)L != plen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm.length must equal S*L"); return NULL; }
+    size_t l0 = 0, l1 = 0, l2 = 0; void *p0 = NULL, *p1 = NULL, *p2 = NULL;
+    if (!get_typed(env, argv[7], napi_float32_array, &p0, &l0, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 8 && !get_typed(env, argv[8], napi_uint8_array, &p1, &l1, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 9 && !get_typed(env, argv[9], napi_uint8_array, &p2, &l2, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outIndex must be a Uint8Array"); return NULL; }
+    int64_t C = emspec_num_columns(L, n, hop);
+    size_t cells = p0 ? l0 : (p1 ? l1 / 4 : l2);
+    if (C <= 0 || cells == 0 || cells % ((size_t)S * (size_t)C) != 0 || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold S*columns*rows cells (rgba: 4 bytes per cell)");
+        return NULL;
+    }
+    batch_job* j = (batch_job*)calloc(1, sizeof(batch_job));
+    if (!j) { napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "calloc"); return NULL; }
+    j->e = h->e; j->pcm = (const float*)pcm; j->S = S; j->L = L; j->n = n; j->hop = hop; j->reassign = reassign ? 1 : 0; j->C = C;
+    j->out.db = (float*)p0; j->out.rgba = (uint8_t*)p1; j->out.index = (uint8_t*)p2;
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j); napi_throw_error(env, "EMSPEC_NAPI", "napi_create_promise"); return NULL; }
+    napi_create_reference(env, argv[1], 1, &j->refs[0]);                       /* keep the buffers alive */
+    if (p0) napi_create_reference(env, argv[7], 1, &j->refs[1]);
+    if (p1) napi_create_reference(env, argv[8], 1, &j->refs[2]);
+    if (p2) napi_create_reference(env, argv[9], 1, &j->refs[3]);
+    napi_create_string_utf8(env, "emspec.batchAsync", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, batch_execute, batch_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        for (int i = 0; i < 4; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+        free(j);
+        napi_throw_error(env, "EMSPEC_NAPI", "could not queue async work");
+        return NULL;
+    }
+    return promise;
+}
+
 static napi_value SetColormap(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -297,6 +385,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"flush", NULL, Flush, NULL, NULL, NULL, napi_default, NULL},
         {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
+        {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
         {"setRowEdges", NULL, SetRowEdges, NULL, NULL, NULL, napi_default, NULL},
         {"getRowEdges", NULL, GetRowEdges, NULL, NULL, NULL, napi_default, NULL},

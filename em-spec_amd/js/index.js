@@ -49,6 +49,12 @@ class Engine {
     return native.batch(this._h, pcm, S, L, fftSize, hop, !!reassign, out.db, out.rgba, out.index);
   }
 
+  /** Same as computeColumns, off the JS thread: resolves with C.  Do not touch the arrays or this
+   *  engine until the promise settles (an engine is not thread-safe). */
+  computeColumnsAsync(pcm, S, L, fftSize, hop, reassign, out) {
+    return native.batchAsync(this._h, pcm, S, L, fftSize, hop, !!reassign, out.db, out.rgba, out.index);
+  }
+
   setColormap(rgba256) { native.setColormap(this._h, rgba256); }
 
   /** Install any strictly increasing frequency axis: Float32Array(rows+1) of edges in Hz; null = log axis. */

@@ -46,8 +46,35 @@ function check(fftSize, hop, reassign, frames) {
   return worst;
 }
 
+async function checkAsync() {
+  const eng = em.createEngine({});
+  const fftSize = 4096, hop = 256, frames = 24, L = fftSize + hop * (frames - 1);
+  const pcm = synth(L);
+  const a = new Float32Array(frames * eng.rows), b = new Float32Array(frames * eng.rows);
+  eng.computeColumns(pcm, 1, L, fftSize, hop, true, { db: a });
+  const C = await eng.computeColumnsAsync(pcm, 1, L, fftSize, hop, true, { db: b });
+  if (C !== frames) throw new Error('async column count');
+  let worst = 0;
+  for (let i = 0; i < a.length; i++) worst = Math.max(worst, Math.abs(a[i] - b[i]));
+  if (!(worst < 2e-4)) throw new Error('async vs sync mismatch ' + worst);
+  let rejected = false;
+  try { await eng.computeColumnsAsync(pcm, 1, L, 3000, hop, true, { db: b }); } catch (e) { rejected = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!rejected) throw new Error('async error path');
+  const edges = em.warpedEdges(eng.rows, 30, 20000, 2.0, 1.5);
+  eng.setRowEdges(edges);
+  const got = eng.getRowEdges();
+  for (let i = 0; i < edges.length; i++) if (got[i] !== edges[i]) throw new Error('row edges round trip');
+  const hz = eng.rowToHz(0.5);
+  if (!(hz > edges[0] && hz < edges[1])) throw new Error('rowToHz');
+  eng.setRowEdges(null);
+  eng.setColormap(em.makeColormap(0.44));
+  eng.destroy();
+}
+
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);
 const col = em.computeSpectrogramColumn(new Float32Array(1024), 1024, 256, false);
 if (col.length !== 1024) throw new Error('module-level call');
-console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2));
+checkAsync().then(() => {
+  console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2));
+}).catch((e) => { console.error(e); process.exit(1); });
