@@ -74,6 +74,25 @@ def cpu_baseline(n, hop, seconds_target=12.0):
                       f"oracle float32 bit model, OpenMP {cores} threads, {dt:.1f} s"}
 
 
+def js_baseline(n, hop, seconds=5.0):
+    """Plain-JS restatement under node (oracle/js/reassign_ref.js), one thread: the closest proxy for the
+    reference's JS/WebAudio CPU path that can exist here (CPU baseline plan item 3)."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        return None
+    try:
+        out = subprocess.run([node, os.path.join(ROOT, "oracle", "js", "reassign_ref.js"), "bench", str(n), str(hop),
+                              str(seconds)], capture_output=True, text=True, timeout=120).stdout
+        d = json.loads(out.strip().splitlines()[-1])
+        return {"value": d["columns_per_s"], "unit": "columns/s", "cores": 1, "kind": "port",
+                "sample": f"{d['columns']} columns of one stream (N={n}, hop={hop}, reassign on), plain JavaScript "
+                          f"restatement (three windowed FFTs, float64) under node {d['node']}, {d['seconds']:.1f} s"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +244,7 @@ def main():
             line["config"]["single_stream_columns_per_s"] = C * reps / (time.perf_counter() - t1)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, hop)
+            line["cpu_baseline_js"] = js_baseline(n, hop)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
