@@ -23,7 +23,7 @@ SYMBOLS = [
     "emspec_num_columns", "emspec_latency_columns", "emspec_column", "emspec_column_flush", "emspec_reset",
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
     "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
-    "emspec_get_row_edges_hz",
+    "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free",
 ]
 
 
@@ -80,9 +80,40 @@ def load():
     lib.emspec_uses_fused.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.emspec_set_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.emspec_get_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.emspec_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.emspec_host_free.argtypes = [C.c_void_p]
+    lib.emspec_host_free.restype = None
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
+
+
+class PinnedArray:
+    """numpy array backed by page-locked host memory from emspec_host_alloc (freed on close/del)."""
+
+    def __init__(self, shape, dtype):
+        lib = load()
+        self._lib = lib
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self._ptr = C.c_void_p()
+        rc = lib.emspec_host_alloc(n, C.byref(self._ptr))
+        if rc != OK:
+            raise EmspecError(rc, "emspec_host_alloc failed")
+        buf = (C.c_char * n).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            self.array = None
+            self._lib.emspec_host_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def default_config(**kw):
@@ -173,13 +204,14 @@ class Engine:
         return tw, eb
 
     # -- batch, host buffers ------------------------------------------------
-    def batch(self, pcm, n, hop, reassign=True, want=("db",)):
+    def batch(self, pcm, n, hop, reassign=True, want=("db",), db_out=None):
         pcm = np.ascontiguousarray(pcm, np.float32)
         if pcm.ndim == 1:
             pcm = pcm[None]
         S, L = pcm.shape
         Cn = num_columns(L, n, hop)
-        db = np.empty((S, Cn, self.rows), np.float32) if "db" in want else None
+        db = (db_out if db_out is not None else np.empty((S, Cn, self.rows), np.float32)) if "db" in want else None
+        assert db is None or (db.shape == (S, Cn, self.rows) and db.dtype == np.float32 and db.flags.c_contiguous)
         rgba = np.empty((S, Cn, self.rows, 4), np.uint8) if "rgba" in want else None
         idx = np.empty((S, Cn, self.rows), np.uint8) if "index" in want else None
         out = Out(_np_ptr(db), _np_ptr(rgba), _np_ptr(idx))

@@ -352,6 +352,26 @@ static napi_value GetRowEdges(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* allocPinned(byteLength) -> ArrayBuffer backed by page-locked host memory (emspec_host_alloc);
+ * typed arrays over it make batch()/column() copies run at full PCIe speed.  Freed by the GC. */
+static void finalize_pinned(napi_env env, void* data, void* hint) { (void)env; (void)hint; emspec_host_free(data); }
+static napi_value AllocPinned(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int64_t bytes = 0;
+    if (argc < 1 || napi_get_value_int64(env, argv[0], &bytes) != napi_ok || bytes <= 0) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "allocPinned(byteLength > 0)"); return NULL; }
+    void* p = NULL;
+    int rc = emspec_host_alloc((size_t)bytes, &p);
+    if (rc != EMSPEC_OK) { napi_throw_error(env, status_name(rc), "page-locked allocation failed"); return NULL; }
+    napi_value ab;
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, finalize_pinned, NULL, &ab) != napi_ok) {
+        emspec_host_free(p);
+        napi_throw_error(env, "EMSPEC_NAPI", "napi_create_external_arraybuffer failed");
+        return NULL;
+    }
+    return ab;
+}
+
 static napi_value NumColumns(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -389,6 +409,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
         {"setRowEdges", NULL, SetRowEdges, NULL, NULL, NULL, napi_default, NULL},
         {"getRowEdges", NULL, GetRowEdges, NULL, NULL, NULL, napi_default, NULL},
+        {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},
         {"numColumns", NULL, NumColumns, NULL, NULL, NULL, napi_default, NULL},
         {"latencyColumns", NULL, LatencyColumns, NULL, NULL, NULL, napi_default, NULL},
     };

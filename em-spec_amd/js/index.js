@@ -109,6 +109,8 @@ module.exports = {
   Engine,
   createEngine: (config) => new Engine(config),
   computeSpectrogramColumn,
+  /** ArrayBuffer of page-locked host memory: typed arrays over it move at full PCIe speed. */
+  allocPinned: native.allocPinned,
   warpedEdges,
   makeColormap,
   numColumns: native.numColumns,

@@ -28,6 +28,7 @@
 #ifndef EMSPEC_H
 #define EMSPEC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -148,6 +149,14 @@ int emspec_reset(emspec_engine* e);
  */
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
                  int32_t n, int32_t hop, int32_t reassign, const emspec_out* out);
+
+/*
+ * Page-locked host memory for the buffers of emspec_batch / emspec_column: copies from and to it
+ * run at full PCIe speed (pageable memory is staged by the runtime at roughly half that).  Optional:
+ * any host memory works.  Needs no engine; free with emspec_host_free.
+ */
+int emspec_host_alloc(size_t bytes, void** out);
+void emspec_host_free(void* p);
 
 /*
  * Same, device-resident: pcm and the outputs are device pointers on the

@@ -17,6 +17,15 @@ dt = time.perf_counter() - t0
 C = out["db"].shape[1]
 print(f"emspec_batch (host buffers, pageable, PCIe in+out): {8 * C / dt:.3e} columns/s "
       f"({dt * 1e3:.1f} ms for 8 streams x {C} columns; {pcm.nbytes / 1e6:.0f} MB in, {out['db'].nbytes / 1e6:.0f} MB out)")
+pin_in = emspec.PinnedArray(pcm.shape, np.float32)
+pin_out = emspec.PinnedArray(out["db"].shape, np.float32)
+pin_in.array[...] = pcm
+e.batch(pin_in.array, n, hop, True, want=("db",), db_out=pin_out.array)
+t0 = time.perf_counter()
+e.batch(pin_in.array, n, hop, True, want=("db",), db_out=pin_out.array)
+dt = time.perf_counter() - t0
+assert np.max(np.abs(pin_out.array - out["db"])) < 2e-4
+print(f"emspec_batch (host buffers from emspec_host_alloc, pinned, PCIe in+out): {8 * C / dt:.3e} columns/s ({dt * 1e3:.1f} ms)")
 e.reset()
 fr = pcm[0]
 for j in range(20):
