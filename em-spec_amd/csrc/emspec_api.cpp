@@ -57,6 +57,12 @@ struct emspec_engine {
     size_t frame_bytes = 0;
     float* d_coldb = nullptr;
     uint8_t* d_colrgba = nullptr;
+    // display post-process (emspec_set_display)
+    float smoothing = 0.0f, agc = 0.0f;
+    float* d_raw = nullptr; size_t raw_bytes = 0;      // raw dB columns of a batch
+    float* d_post = nullptr; size_t post_bytes = 0;    // post-processed dB when the caller wants none
+    float* d_peak = nullptr; size_t peak_bytes = 0;    // column peaks + gains
+    float* d_pstate = nullptr;                         // streaming: [0]=AGC level, [1]=initialised, [2..]=previous column
 };
 
 namespace {
@@ -230,6 +236,7 @@ void emspec_destroy(emspec_engine* e) {
     drop_plans(e);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
+    (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak); (void)hipFree(e->d_pstate);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     delete e;
@@ -331,6 +338,22 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     const DbMap m = db_map(e, n);
     const int64_t C = emspec_num_columns(L, n, hop);
     if (!db && !rgba && !index) return EMSPEC_OK;
+    if (e->smoothing > 0.0f || e->agc > 0.0f) {
+        // raw dB columns into a workspace, then AGC + temporal smoothing into the caller's buffers
+        const size_t cells = (size_t)S * C * e->cfg.rows;
+        if ((rc = grow(e, (void**)&e->d_raw, &e->raw_bytes, cells * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_peak, &e->peak_bytes, (size_t)S * C * 8 + 16))) return rc;
+        float* outdb = db;
+        if (!outdb) { if ((rc = grow(e, (void**)&e->d_post, &e->post_bytes, cells * 4))) return rc; outdb = e->d_post; }
+        const float sm = e->smoothing, ag = e->agc;
+        e->smoothing = 0.0f; e->agc = 0.0f;     // run the plain path into the workspace
+        rc = emspec_batch_device(e, pcm, S, L, n, hop, reassign, e->d_raw, nullptr, nullptr, hip_stream);
+        e->smoothing = sm; e->agc = ag;
+        if (rc) return rc;
+        HIPCHK(e, launch_postprocess(e->d_raw, outdb, rgba, index, S, C, e->cfg.rows, sm, ag, e->cfg.db_top, m, e->d_lut,
+                                     e->d_peak, e->d_peak + (size_t)S * C, st));
+        return EMSPEC_OK;
+    }
     if (fused_supported(n, hop, e->cfg.rows, reassign)) {
         HIPCHK(e, launch_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
         return EMSPEC_OK;
@@ -527,8 +550,18 @@ int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
     return EMSPEC_OK;
 }
 
+int emspec_set_display(emspec_engine* e, float smoothing, float agc_strength) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    if (!(smoothing >= 0.0f && smoothing <= 0.95f) || !(agc_strength >= 0.0f && agc_strength <= 1.0f))
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "smoothing must be in [0,0.95], agc_strength in [0,1]");
+    e->smoothing = smoothing;
+    e->agc = agc_strength;
+    return EMSPEC_OK;
+}
+
 int emspec_reset(emspec_engine* e) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
+    if (e->d_pstate) { (void)hipSetDevice(e->device); (void)hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream); }
     e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0;
     e->st_fed = 0; e->st_emitted = 0;
     return EMSPEC_OK;
@@ -541,8 +574,17 @@ static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_
     const int64_t slot = c < 0 ? W : c % W;
     const DbMap m = db_map(e, e->st_n);
     float* cells = e->d_ring + (size_t)slot * R;
-    HIPCHK(e, launch_finalize(cells, R, m, e->d_lut, out_db ? e->d_coldb : nullptr, out_rgba ? e->d_colrgba : nullptr,
-                              nullptr, e->stream));
+    const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
+    HIPCHK(e, launch_finalize(cells, R, m, e->d_lut, (out_db || post) ? e->d_coldb : nullptr,
+                              (out_rgba && !post) ? e->d_colrgba : nullptr, nullptr, e->stream));
+    if (post) {
+        if (!e->d_pstate) {
+            HIPCHK(e, hipMalloc(&e->d_pstate, (size_t)(4096 + 4) * 4));
+            HIPCHK(e, hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream));
+        }
+        HIPCHK(e, launch_post_column(e->d_coldb, R, e->smoothing, e->agc, e->cfg.db_top, m, e->d_lut,
+                                     out_rgba ? e->d_colrgba : nullptr, e->d_pstate, e->d_pstate + 4, e->stream));
+    }
     if (out_db) HIPCHK(e, hipMemcpyAsync(out_db, e->d_coldb, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
     if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba, e->d_colrgba, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
     if (c >= 0) HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)R * 4, e->stream));

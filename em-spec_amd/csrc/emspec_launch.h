@@ -44,6 +44,12 @@ hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t*
                         const float* pcm, int64_t L, int S, int64_t total_cols,
                         float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
                         unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
+// display post-process (AGC + temporal smoothing) over finished columns, see post.hip.inc
+hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uint8_t* index, int S, int64_t C, int R,
+                              float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut, float* peak,
+                              float* gain, hipStream_t st);
+hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut,
+                              uint8_t* rgba, float* state, float* yprev, hipStream_t st);
 bool fused_supported(int n, int hop, int rows, int reassign);
 int fused_waves_per_group();
 int fused_read_errflag();   // non-zero if a bounded spin of the decoupled-team kernel ever timed out

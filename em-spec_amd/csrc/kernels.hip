@@ -358,3 +358,4 @@ hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh,
 }  // namespace emspec
 
 #include "fused.hip.inc"
+#include "post.hip.inc"

@@ -23,7 +23,7 @@ SYMBOLS = [
     "emspec_num_columns", "emspec_latency_columns", "emspec_column", "emspec_column_flush", "emspec_reset",
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
     "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
-    "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free",
+    "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free", "emspec_set_display",
 ]
 
 
@@ -83,6 +83,7 @@ def load():
     lib.emspec_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     lib.emspec_host_free.argtypes = [C.c_void_p]
     lib.emspec_host_free.restype = None
+    lib.emspec_set_display.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
@@ -183,6 +184,10 @@ class Engine:
         lut = np.ascontiguousarray(lut, np.uint8)
         assert lut.shape == (256, 4)
         self._chk(self._lib.emspec_set_colormap(self._h, _np_ptr(lut)))
+
+    def set_display(self, smoothing=0.0, agc_strength=0.0):
+        """Temporal smoothing in [0,0.95] and adaptive-brightness strength in [0,1]; (0,0) = off."""
+        self._chk(self._lib.emspec_set_display(self._h, smoothing, agc_strength))
 
     def set_row_edges_hz(self, edges_hz):
         """rows+1 strictly increasing edges in Hz, or None for the configured log axis."""

@@ -330,6 +330,17 @@ static napi_value SetColormap(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+static napi_value SetDisplay(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    double sm = 0, agc = 0;
+    if (argc < 3 || napi_get_value_double(env, argv[1], &sm) != napi_ok || napi_get_value_double(env, argv[2], &agc) != napi_ok) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "setDisplay(handle, smoothing, agcStrength)"); return NULL; }
+    int rc = emspec_set_display(h->e, (float)sm, (float)agc);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
 /* setRowEdges(handle, Float32Array(rows+1) | null) ; getRowEdges(handle, Float32Array(rows+1)) */
 static napi_value SetRowEdges(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
@@ -407,6 +418,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
+        {"setDisplay", NULL, SetDisplay, NULL, NULL, NULL, napi_default, NULL},
         {"setRowEdges", NULL, SetRowEdges, NULL, NULL, NULL, napi_default, NULL},
         {"getRowEdges", NULL, GetRowEdges, NULL, NULL, NULL, napi_default, NULL},
         {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},

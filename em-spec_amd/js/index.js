@@ -57,6 +57,9 @@ class Engine {
 
   setColormap(rgba256) { native.setColormap(this._h, rgba256); }
 
+  /** Temporal smoothing (0..0.95) and adaptive brightness / AGC strength (0..1); 0,0 = off. */
+  setDisplay(smoothing = 0, agcStrength = 0) { native.setDisplay(this._h, smoothing, agcStrength); }
+
   /** Install any strictly increasing frequency axis: Float32Array(rows+1) of edges in Hz; null = log axis. */
   setRowEdges(edgesHz) { native.setRowEdges(this._h, edgesHz); }
   /** The axis in use (rows+1 edges in Hz): the inverse map for the shift+hover frequency read-out. */

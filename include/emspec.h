@@ -111,6 +111,17 @@ int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba256x4);
 int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count);
 int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count);
 
+/*
+ * Display post-process over finished columns, per stream and in time order (README.md:14 "adaptive
+ * brightness", README.md:50 "temporal smoothing"; laws [BUILD-DEFINED]):
+ *   agc_strength in [0,1]: a column-peak follower (fast attack, slow release) shifts every column by
+ *                          agc_strength * (db_top - level) dB, limited to +-40 dB;
+ *   smoothing    in [0,0.95]: y[c] = smoothing*y[c-1] + (1-smoothing)*x[c] per row, on the dB values.
+ * Both 0 (the default) = off.  Applies to emspec_batch / _device and to the streaming call (whose
+ * state emspec_reset clears).  The dB output is the post-processed value; index and RGBA follow it.
+ */
+int emspec_set_display(emspec_engine* e, float smoothing, float agc_strength);
+
 /* Number of columns a stream of L samples yields: (L-n)/hop+1, or 0. */
 int64_t emspec_num_columns(int64_t L, int32_t n, int32_t hop);
 

@@ -136,3 +136,34 @@ def batch_f32(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
 
 def max_threads():
     return lib().eo_max_threads()
+
+
+def postprocess(db, smoothing, agc, cfg, lut=None):
+    """numpy restatement of the display post-process (post.hip.inc): db [S][C][R]
+    raw dB columns -> (db', index, rgba).  float32 arithmetic in the same order as the kernels."""
+    f = np.float32
+    db = np.asarray(db, f)
+    S, Cn, R = db.shape
+    out = np.empty_like(db)
+    sm, ag, top = f(smoothing), f(agc), f(cfg.db_top)
+    up, down, gmax = f(0.25), f(0.02), f(40.0)
+    for s in range(S):
+        m = db[s].max(axis=1)
+        p = m[0]
+        y = None
+        for c in range(Cn):
+            g = f(0.0)
+            if ag > 0:
+                d = f(m[c] - p)
+                p = f(p + (up if d > 0 else down) * d)
+                g = f(min(max(f(ag * f(top - p)), -gmax), gmax))
+            x = (db[s, c] + g).astype(f)
+            y = x if y is None else (sm * y + f(f(1.0) - sm) * x).astype(f)
+            out[s, c] = y
+    lo = f(cfg.db_top - cfg.db_range)
+    inv = f(1.0 / float(cfg.db_range))
+    v = np.clip((out - lo) * inv, f(0), f(1)).astype(f)
+    v[out < f(cfg.gate_db)] = 0
+    idx = (v * f(255.0) + f(0.5)).astype(np.int32).astype(np.uint8)
+    lut = default_lut() if lut is None else lut
+    return out, idx, lut[idx]

@@ -352,3 +352,42 @@ def test_no_spin_timeouts(engine):
     lib = emspec.load()
     lib.emspec_debug_fused_error.argtypes = [C.c_void_p]
     assert lib.emspec_debug_fused_error(engine._h) == 0
+
+
+@pytest.mark.parametrize("smoothing,agc", [(0.6, 0.0), (0.0, 1.0), (0.85, 0.7)])
+def test_display_postprocess(smoothing, agc):
+    """Temporal smoothing + adaptive brightness over finished columns: batch (chunked IIR with
+    warm-up, > 1 chunk) and the streaming call must both match the sequential numpy restatement."""
+    import emspec
+    n, hop = 1024, 256                 # generic path, cheap oracle; C spans several 1024-column chunks
+    frames = 2600
+    rng = np.random.default_rng(3)
+    pcm = synth.streams(2, n + hop * (frames - 1))
+    pcm *= (0.05 + 0.95 * (np.sin(np.arange(pcm.shape[1]) / 40000.0) ** 2)).astype(np.float32)   # loudness swells: AGC has work
+    cfg = O.make_cfg(n, hop, True)
+    raw, _, _ = O.batch_f32(cfg, pcm, want=("db",))
+    want_db, want_idx, want_rgba = O.postprocess(raw, smoothing, agc, cfg)
+    with emspec.Engine() as e:
+        e.set_display(smoothing, agc)
+        out = e.batch(pcm, n, hop, True, want=("db", "index", "rgba"))
+        assert np.max(np.abs(out["db"] - want_db)) < 2e-3
+        d = np.abs(out["index"].astype(int) - want_idx.astype(int))
+        assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+        assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
+        only_idx = e.batch(pcm[:1], n, hop, True, want=("index",))["index"]       # no dB buffer from the caller
+        assert np.array_equal(only_idx, out["index"][:1])
+        # streaming: same law, state carried in the engine
+        D = emspec.latency_columns(n, hop, True)
+        got = []
+        for j in range(300):
+            db, c = e.column(pcm[0, j * hop:j * hop + n], hop, True)
+            if c >= 0:
+                got.append(db)
+        got = np.stack(got)
+        assert np.max(np.abs(got - want_db[0, :got.shape[0]])) < 2e-3
+        e.reset()
+        e.set_display(0.0, 0.0)
+        plain = e.batch(pcm[:1, :n + hop * 50], n, hop, True, want=("db",))["db"]
+        assert np.max(np.abs(plain[:, :40] - raw[:1, :40])) < 8.7e-4      # (later columns lack their future frames)
+        with pytest.raises(emspec.EmspecError):
+            e.set_display(0.99, 0.0)
