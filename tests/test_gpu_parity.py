@@ -391,3 +391,43 @@ def test_display_postprocess(smoothing, agc):
         assert np.max(np.abs(plain[:, :40] - raw[:1, :40])) < 8.7e-4      # (later columns lack their future frames)
         with pytest.raises(emspec.EmspecError):
             e.set_display(0.99, 0.0)
+
+
+@pytest.mark.parametrize("kind", ["sine", "impulses", "dc_plus_nyquist", "loud"])
+def test_heavy_cell_contention(engine, kind):
+    """Signals that pile many bins into few histogram cells (the exchange-based LDS accumulate is
+    exercised at its worst: a stationary sine sends its whole main lobe and skirts of up to 17 frames
+    into ONE cell; an impulse train puts all 2049 bins of 16 frames into one column)."""
+    n, hop, frames = 4096, 256, 80
+    L = n + hop * (frames - 1)
+    t = np.arange(L)
+    if kind == "sine":
+        x = 0.9 * np.sin(2 * np.pi * 3000.0 * t / 48000.0)
+    elif kind == "impulses":
+        x = np.zeros(L)
+        x[1000::4096] = 1.0
+    elif kind == "dc_plus_nyquist":
+        x = 0.5 + 0.4 * np.cos(np.pi * t)          # energy exactly at k = 0 and k = N/2: both are dropped by the axis
+    else:
+        x = 30.0 * np.sin(2 * np.pi * 440.0 * t / 48000.0) + 5.0 * np.sign(np.sin(2 * np.pi * 97.0 * t / 48000.0))   # far outside [-1,1]
+    pcm = np.stack([x, 0.5 * x]).astype(np.float32)
+    out = engine.batch(pcm, n, hop, True, want=("db", "index"))
+    cfg = O.make_cfg(n, hop, True)
+    odb, _, oidx = O.batch_f32(cfg, pcm, want=("db", "index"))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    assert np.abs(out["index"].astype(int) - oidx.astype(int)).max() <= 1
+    if kind == "sine":      # physical check: the peak cell carries the sine's energy, 20 log10(0.9) dB
+        assert abs(out["db"][0, 40].max() - 20 * np.log10(0.9)) < 0.05
+
+
+@pytest.mark.parametrize("rows", [2048, 4096])
+def test_generic_path_at_4096_with_many_rows(rows):
+    """N = 4096 / hop 256 with more rows than the fused ring holds: the records + tile-scatter path."""
+    import emspec
+    n, hop, frames = 4096, 256, 45
+    pcm = synth.streams(1, n + hop * (frames - 1))
+    with emspec.Engine(rows=rows) as e:
+        assert not e.fused(n, hop, True)
+        out = e.batch(pcm, n, hop, True, want=("db",))
+    odb, _, _ = O.batch_f32(O.make_cfg(n, hop, True, rows=rows), pcm, want=("db",))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
