@@ -27,6 +27,19 @@ namespace emspec {
 // Middle-pass twiddles depend on the low B0 bits of the thread id only: 15 << B0 entries per
 // pass (<= 1020 in total), staged once per workgroup in LDS instead of 15 global loads per
 // thread per pass.
+// Natural-order buffer swizzle.  In the rewrite after the last pass the 16 lanes of a write group
+// hold k's that differ in bits [LOG2N-5 .. LOG2N-8] only (bit-reversed thread id), i.e. 2^(LOG2N-8)
+// slots apart: a 16-way bank conflict in a plain buffer.  XOR-ing those bits into the low bits makes
+// the group hit 16 distinct positions; reads by consecutive k stay conflict-free (the XOR source is
+// constant, or a bijection, across 32 consecutive k).
+template <int LOG2N>
+__device__ __forceinline__ int natpos(int k) {
+    if constexpr (LOG2N >= 12) return k ^ ((k >> (LOG2N - 8)) & 15);
+    else if constexpr (LOG2N == 11) return k ^ ((k >> 4) & 7);
+    else if constexpr (LOG2N == 10) return k ^ ((k >> 4) & 3);
+    else return k;
+}
+
 constexpr int mid_tw_entries(int log2n) {
     int s0 = 4, n = 0;
     while (log2n - s0 > 4) { n += 15 << (log2n - s0 - 4); s0 += 4; }
@@ -78,7 +91,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
             for (int i = 0; i < (1 << R); ++i) {
                 const unsigned p = (unsigned)((g << R) + i);
                 const unsigned k = __brev(p) >> (32 - LOG2N);
-                sm[k] = v[gi][i];
+                sm[natpos<LOG2N>((int)k)] = v[gi][i];
             }
         }
         __syncthreads();
@@ -127,8 +140,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     for (int i = 0; i < 9; ++i) {
         const int k = t + T * i;
         if (k > N / 2) break;
-        const float2 zm = sm[(k - 1) & (N - 1)], z0 = sm[k], zp = sm[k + 1];
-        const float2 wm = sm[(N - k + 1) & (N - 1)], w0 = sm[(N - k) & (N - 1)], wp = sm[N - k - 1];
+        const float2 zm = sm[natpos<LOG2N>((k - 1) & (N - 1))], z0 = sm[natpos<LOG2N>(k)], zp = sm[natpos<LOG2N>(k + 1)];
+        const float2 wm = sm[natpos<LOG2N>((N - k + 1) & (N - 1))], w0 = sm[natpos<LOG2N>((N - k) & (N - 1))],
+                     wp = sm[natpos<LOG2N>(N - k - 1)];
         const BinOut o = reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
         const int64_t col = jcol + o.dcol;
         if (sk.power) {
