@@ -242,6 +242,38 @@ def main():
                 eng.batch_device(one, n, hop, True, db=db[:1], index=idx[:1], stream=cur)
             torch.cuda.synchronize(dev)
             line["config"]["single_stream_columns_per_s"] = C * reps / (time.perf_counter() - t1)
+        if world == 1 and args.workload == "batch64":
+            # the per-bin parity dump (power, column, row for every bin: what the exact-index criterion forces
+            # to exist in HBM, BASELINE.md "parity mode") timed on 16 of the streams, as a second roofline point
+            import ctypes as C_
+            lib = emspec.load()
+            Sd, Ld = 16, 1 << 20
+            Cd, K = emspec.num_columns(Ld, n, hop), n // 2 + 1
+            sub = pcm[:Sd, :Ld].contiguous()
+            pw_ = torch.empty((Sd, Cd, K), dtype=torch.float32, device=dev)
+            cl_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+            rw_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+
+            def dump():
+                rc = lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(),
+                                                   cl_.data_ptr(), rw_.data_ptr(), C_.c_void_p(cur.cuda_stream))
+                assert rc == 0
+            dump()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for _ in range(5):
+                dump()
+            e1.record(cur)
+            torch.cuda.synchronize(dev)
+            dms = e0.elapsed_time(e1) / 5
+            bpc = 4 * hop + 12 * K
+            line["roofline_parity_dump"] = {
+                "bound": "hbm", "achieved": Sd * Cd * bpc / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": Sd * Cd * bpc / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_column": bpc,
+                "columns_per_s": Sd * Cd / (dms * 1e-3), "kernel": "frames_kernel<12> (emspec_parity_dump_device)",
+                "note": "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples"}
+            del pw_, cl_, rw_
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, hop)
             line["cpu_baseline_js"] = js_baseline(n, hop)
