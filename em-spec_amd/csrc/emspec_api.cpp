@@ -324,36 +324,13 @@ int emspec_get_tables(emspec_engine* e, int32_t n, float* edges, float* tw) {
     return EMSPEC_OK;
 }
 
-int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
-                        int32_t reassign, float* db, uint8_t* rgba, uint8_t* index, void* hip_stream) {
-    if (!e || !pcm) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
-    int rc = check_shape(e, n, hop);
-    if (rc) return rc;
-    if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
-    HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP default stream
-    Plan* p;
-    if ((rc = get_plan(e, n, &p))) return rc;
-    const PlanDev pd = plan_dev(e, *p, hop, reassign);
-    const DbMap m = db_map(e, n);
-    const int64_t C = emspec_num_columns(L, n, hop);
-    if (!db && !rgba && !index) return EMSPEC_OK;
-    if (e->smoothing > 0.0f || e->agc > 0.0f) {
-        // raw dB columns into a workspace, then AGC + temporal smoothing into the caller's buffers
-        const size_t cells = (size_t)S * C * e->cfg.rows;
-        if ((rc = grow(e, (void**)&e->d_raw, &e->raw_bytes, cells * 4))) return rc;
-        if ((rc = grow(e, (void**)&e->d_peak, &e->peak_bytes, (size_t)S * C * 8 + 16))) return rc;
-        float* outdb = db;
-        if (!outdb) { if ((rc = grow(e, (void**)&e->d_post, &e->post_bytes, cells * 4))) return rc; outdb = e->d_post; }
-        const float sm = e->smoothing, ag = e->agc;
-        e->smoothing = 0.0f; e->agc = 0.0f;     // run the plain path into the workspace
-        rc = emspec_batch_device(e, pcm, S, L, n, hop, reassign, e->d_raw, nullptr, nullptr, hip_stream);
-        e->smoothing = sm; e->agc = ag;
-        if (rc) return rc;
-        HIPCHK(e, launch_postprocess(e->d_raw, outdb, rgba, index, S, C, e->cfg.rows, sm, ag, e->cfg.db_top, m, e->d_lut,
-                                     e->d_peak, e->d_peak + (size_t)S * C, st));
-        return EMSPEC_OK;
-    }
+}  // extern "C"
+
+// columns of S device-resident streams -> dB / RGBA / index, no display post-process
+static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, const float* pcm, int32_t S, int64_t L,
+                       int32_t n, int32_t hop, int32_t reassign, int64_t C, float* db, uint8_t* rgba, uint8_t* index,
+                       hipStream_t st) {
+    int rc;
     if (fused_supported(n, hop, e->cfg.rows, reassign)) {
         HIPCHK(e, launch_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
         return EMSPEC_OK;
@@ -376,6 +353,37 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
                                       index ? index + s0 * col_cells : nullptr, st));
     }
     return EMSPEC_OK;
+}
+
+extern "C" {
+
+int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                        int32_t reassign, float* db, uint8_t* rgba, uint8_t* index, void* hip_stream) {
+    if (!e || !pcm) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)hip_stream;   // NULL = the HIP default stream
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    const DbMap m = db_map(e, n);
+    const int64_t C = emspec_num_columns(L, n, hop);
+    if (!db && !rgba && !index) return EMSPEC_OK;
+    if (e->smoothing > 0.0f || e->agc > 0.0f) {
+        // raw dB columns into a workspace, then AGC + temporal smoothing into the caller's buffers
+        const size_t cells = (size_t)S * C * e->cfg.rows;
+        if ((rc = grow(e, (void**)&e->d_raw, &e->raw_bytes, cells * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_peak, &e->peak_bytes, (size_t)S * C * 8 + 16))) return rc;
+        float* outdb = db;
+        if (!outdb) { if ((rc = grow(e, (void**)&e->d_post, &e->post_bytes, cells * 4))) return rc; outdb = e->d_post; }
+        if ((rc = run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, e->d_raw, nullptr, nullptr, st))) return rc;
+        HIPCHK(e, launch_postprocess(e->d_raw, outdb, rgba, index, S, C, e->cfg.rows, e->smoothing, e->agc,
+                                     e->cfg.db_top, m, e->d_lut, e->d_peak, e->d_peak + (size_t)S * C, st));
+        return EMSPEC_OK;
+    }
+    return run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, db, rgba, index, st);
 }
 
 // Diagnostic: non-zero if a bounded spin of the decoupled-team fused kernel ever timed out on this device.
