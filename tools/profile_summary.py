@@ -28,6 +28,8 @@ for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         continue
     vals = {}
     rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == name and "emspec" in r["Kernel_Name"]]
+    fused = [r for r in rows if "fused4096" in r["Kernel_Name"]]     # the headline kernel, when it ran
+    rows = fused or rows
     big = max(int(r["Grid_Size"]) for r in rows)      # the timed batch launches (bench.py also times one-stream launches)
     for r in rows:
         if int(r["Grid_Size"]) == big:
