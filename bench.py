@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=22)
     ap.add_argument("--chunks", type=int, default=8, help="stream-chunks per step (gather overlap, N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-chunks", type=int, default=0, help="N=1: launch per stream-chunk as the N>1 path does (no gather)")
     ap.add_argument("--reassign", type=int, default=1)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (gather via host tensors)")
@@ -146,7 +147,7 @@ def main():
     db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
     idx = torch.empty((S, C, R), dtype=torch.uint8, device=dev)
 
-    nch = max(1, min(args.chunks, S)) if world > 1 else 1
+    nch = max(1, min(args.chunks, S)) if world > 1 else max(1, min(args.force_chunks, S)) if args.force_chunks else 1
     bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     gathered = None
