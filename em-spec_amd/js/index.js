@@ -100,6 +100,16 @@ function makeColormap(brightness = 0.5, stops = [[0, 0, 0], [80, 0, 80], [200, 5
   return lut;
 }
 
+/** Gradient stop tables for makeColormap().  'reference' is the ramp measured from the reference's
+ *  settings screenshot (SURVEY.md §4); the others are plain conveniences, not claims about the
+ *  reference's other (undocumented) maps. */
+const colormapStops = {
+  reference: [[0, 0, 0], [80, 0, 80], [200, 50, 50], [255, 150, 0], [255, 255, 200]],
+  grayscale: [[0, 0, 0], [255, 255, 255]],
+  ice: [[0, 0, 0], [0, 40, 120], [0, 140, 200], [140, 230, 255], [255, 255, 255]],
+  green: [[0, 0, 0], [0, 70, 20], [40, 180, 60], [200, 255, 140], [255, 255, 255]],
+};
+
 let defaultEngine = null;
 
 /** Drop-in for the renderer: lazily creates one engine with the default configuration. */
@@ -116,6 +126,7 @@ module.exports = {
   allocPinned: native.allocPinned,
   warpedEdges,
   makeColormap,
+  colormapStops,
   numColumns: native.numColumns,
   latencyColumns: native.latencyColumns,
 };
