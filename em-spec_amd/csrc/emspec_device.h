@@ -225,6 +225,23 @@ __device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* e
 // sum back (releases it).  A lane that reads the sentinel lost the race to another lane
 // or wave and retries; no lane holds a cell across a loop iteration, so the loop always
 // drains.  Result: the same float sum as an atomic add, in some order.
+// (diagnostic twin: also counts the loop's rounds, for the stamped build only)
+__device__ __forceinline__ unsigned lds_accumulate_counted(float* cell, float p, bool want) {
+    unsigned* c = reinterpret_cast<unsigned*>(cell);
+    bool todo = want;
+    unsigned rounds = 0;
+    while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+        ++rounds;
+        if (todo) {
+            const unsigned old = __hip_atomic_exchange(c, 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old != 0xFFFFFFFFu) {
+                __hip_atomic_store(cell, __uint_as_float(old) + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                todo = false;
+            }
+        }
+    }
+    return rounds;
+}
 __device__ __forceinline__ void lds_accumulate(float* cell, float p, bool want) {
     unsigned* c = reinterpret_cast<unsigned*>(cell);
     bool todo = want;

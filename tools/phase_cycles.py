@@ -37,6 +37,8 @@ print(f"groups {groups.value}; mean cycles per wave {tot.mean():.0f} (readcyclec
 for i, nm in enumerate(names[:7]):
     v = cyc[:, :, i].astype(np.float64)
     print(f"  {nm:16s} {100 * v.sum() / tot.sum():5.1f} %   per-iteration {v.mean() / ((Cn / (groups.value / S) + 16) / 2):8.0f}")
+it_ = (Cn / (groups.value / S) + 16) / 2
+print(f"accumulate rounds per wave per frame (4 calls): {cyc[:, :, 7].astype(np.float64).mean() / it_:.2f}")
 if len(sys.argv) > 2:
     print("per-wave mean cycles per iteration (rows: wave, cols: phases)")
     it = (Cn / (groups.value / S) + 16) / 2
