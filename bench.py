@@ -145,7 +145,10 @@ def main():
     first_stream, _ = shard.stream_shard(rank, world, world * S)
     pcm = synth_device(S, L, first_stream, dev)
     db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
-    idx = torch.empty((S, C, R), dtype=torch.uint8, device=dev)
+    # N>1: two index buffers, so the gather of step k's last chunks overlaps step k+1's first kernels
+    nbuf = 2 if world > 1 else 1
+    idx_bufs = [torch.empty((S, C, R), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    idx = idx_bufs[0]
 
     nch = max(1, min(args.chunks, S)) if world > 1 else max(1, min(args.force_chunks, S)) if args.force_chunks else 1
     bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
@@ -158,11 +161,19 @@ def main():
     cur = torch.cuda.current_stream(dev)
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    sent = [[None] * nch for _ in range(nbuf)]     # per (buffer, chunk): event after its last gather
+    nstep = [0]
+
     def step(timed_i=None):
+        p = nstep[0] % nbuf
+        nstep[0] += 1
+        ibuf = idx_bufs[p]
         for ci, (a, b) in enumerate(bounds):
+            if sent[p][ci] is not None:
+                cur.wait_event(sent[p][ci])        # the gather that last read this chunk of ibuf
             if timed_i is not None and ci == 0:
                 kev[timed_i][0].record(cur)
-            eng.batch_device(pcm[a:b], n, hop, bool(args.reassign), db=db[a:b], index=idx[a:b], stream=cur)
+            eng.batch_device(pcm[a:b], n, hop, bool(args.reassign), db=db[a:b], index=ibuf[a:b], stream=cur)
             if timed_i is not None and ci == nch - 1:
                 kev[timed_i][1].record(cur)
             if world > 1:
@@ -170,10 +181,10 @@ def main():
                 ready.record(cur)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(ready)
-                    src = idx[a:b] if args.backend == "nccl" else idx[a:b].cpu()   # gloo rehearsal: host tensors
+                    src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
                     shard.gather_columns_into(src, gathered[ci] if rank == 0 else None, dst=0)
-        if world > 1:
-            cur.wait_stream(comm_stream)
+                    sent[p][ci] = torch.cuda.Event()
+                    sent[p][ci].record(comm_stream)
 
     def barrier():
         if world > 1:

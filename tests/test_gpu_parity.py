@@ -431,3 +431,41 @@ def test_generic_path_at_4096_with_many_rows(rows):
         out = e.batch(pcm, n, hop, True, want=("db",))
     odb, _, _ = O.batch_f32(O.make_cfg(n, hop, True, rows=rows), pcm, want=("db",))
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+
+
+@pytest.mark.parametrize("n,hop", [(4096, 256), (16384, 512)])
+def test_dump_vs_hipfft_three_window(engine, n, hop):
+    """an on-device cross-check that shares nothing with the hand-written
+    FFT — three explicitly windowed float64 rfft's through torch.fft (hipFFT/rocFFT on ROCm)."""
+    import torch
+    frames = 16
+    pcm = _pcm(n, hop, frames, S=1)
+    pw, col, row = engine.parity_dump(pcm, n, hop, True, 0, frames)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(pcm[0]).to(dev, torch.float64).unfold(0, n, hop)[:frames]
+    i = torch.arange(n, device=dev, dtype=torch.float64)
+    h = 0.5 - 0.5 * torch.cos(2 * np.pi * i / n)
+    Xh = torch.fft.rfft(x * h)
+    Xt = torch.fft.rfft(x * ((i - n // 2) * h))
+    Xd = torch.fft.rfft(x * ((np.pi / n) * torch.sin(2 * np.pi * i / n)))
+    P = (Xh.real ** 2 + Xh.imag ** 2)
+    Ps = torch.where(P > 0, P, torch.ones_like(P))
+    ts = (Xt * Xh.conj()).real / Ps
+    ks = -(n / (2 * np.pi)) * (Xd * Xh.conj()).imag / Ps
+    P, ts, ks = P.cpu().numpy(), ts.cpu().numpy(), ks.cpu().numpy()
+    strong = P >= P.max(axis=1, keepdims=True) * 1e-6
+    rel = np.abs(pw[0] - P) / np.maximum(P, 1e-300)
+    assert rel[strong].max() < 1e-4, rel[strong].max()
+    cfg = O.make_cfg(n, hop, True)
+    _, eb = O.tables(cfg)
+    D = -(-n // (2 * hop))
+    cf = np.floor(ts / hop + 0.5)
+    khat = np.arange(n // 2 + 1)[None, :] + ks
+    valid = (P >= cfg.power_floor * (n / 4.0) ** 2) & (np.abs(cf) <= D) & (khat >= eb[0]) & (khat < eb[-1])
+    hrow = np.searchsorted(eb.astype(np.float64), khat, side="right") - 1
+    hcol = np.arange(frames)[:, None] + cf
+    # both sides must agree on which bins land at all, up to rare edge cases
+    assert np.mean((row[0] >= 0) != valid) < 2e-3
+    both = valid & (row[0] >= 0)
+    assert np.mean(row[0][both] != hrow[both]) < 2e-3
+    assert np.mean(col[0][both] != hcol[both]) < 2e-3
