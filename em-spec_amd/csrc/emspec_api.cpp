@@ -49,6 +49,14 @@ struct emspec_engine {
     size_t stage_bytes = 0;
     // streaming state
     int st_n = 0, st_hop = 0, st_reassign = -1, st_D = 0;
+    int st_W = 0;             // ring slots (2D+1 per-frame mode, 2D+kPushFrames sample mode); slot st_W is the empty column
+    int st_mode = 0;          // 0 idle, 1 per-frame (emspec_column), 2 per-sample-block (emspec_push_samples)
+    int64_t st_have = 0;      // sample mode: samples buffered in d_sbuf[st_cur], first one is sample st_fed*hop
+    int st_cur = 0;
+    float* d_sbuf[2] = {nullptr, nullptr};
+    size_t sbuf_bytes[2] = {0, 0};
+    float* d_pushdb = nullptr; size_t pushdb_bytes = 0;
+    uint8_t* d_pushrgba = nullptr; size_t pushrgba_bytes = 0;
     int64_t st_fed = 0;       // frames fed so far
     int64_t st_emitted = 0;   // columns emitted so far (flush included)
     float* d_ring = nullptr;  // [W+1][rows]; slot W stays zero (the empty column)
@@ -237,6 +245,7 @@ void emspec_destroy(emspec_engine* e) {
     (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
     (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak); (void)hipFree(e->d_pstate);
+    (void)hipFree(e->d_sbuf[0]); (void)hipFree(e->d_sbuf[1]); (void)hipFree(e->d_pushdb); (void)hipFree(e->d_pushrgba);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     delete e;
@@ -570,15 +579,15 @@ int emspec_set_display(emspec_engine* e, float smoothing, float agc_strength) {
 int emspec_reset(emspec_engine* e) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
     if (e->d_pstate) { (void)hipSetDevice(e->device); (void)hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream); }
-    e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0;
-    e->st_fed = 0; e->st_emitted = 0;
+    e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0; e->st_W = 0; e->st_mode = 0;
+    e->st_fed = 0; e->st_emitted = 0; e->st_have = 0;
     return EMSPEC_OK;
 }
 
 // finalize ring slot of absolute column c (or the empty slot when c < 0), copy out, clear the slot
 static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_rgba) {
     const int R = e->cfg.rows;
-    const int W = 2 * e->st_D + 1;
+    const int W = e->st_W;
     const int64_t slot = c < 0 ? W : c % W;
     const DbMap m = db_map(e, e->st_n);
     float* cells = e->d_ring + (size_t)slot * R;
@@ -612,14 +621,15 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     if (e->st_reassign < 0) {
         // first frame of a stream: set up the ring
         e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = latency(n, hop, reassign);
-        const int W = 2 * e->st_D + 1;
+        e->st_mode = 1;
+        const int W = e->st_W = 2 * e->st_D + 1;
         if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
         if ((rc = grow(e, (void**)&e->d_frame, &e->frame_bytes, (size_t)n * 4))) return rc;
         if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
         if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
         HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
-    } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign) {
-        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign changed mid-stream; call emspec_reset() first");
+    } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 1) {
+        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
     }
     Plan* p;
     if ((rc = get_plan(e, n, &p))) return rc;
@@ -628,7 +638,7 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
     FrameSinks sk;
     sk.hist = e->d_ring;
-    sk.hist_slots = 2 * e->st_D + 1;
+    sk.hist_slots = e->st_W;
     sk.total_cols = INT64_MAX;
     sk.ring = 1;
     sk.col_offset = j;   // the staged frame sits at offset 0 but is absolute frame j
@@ -638,6 +648,124 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     if (out_column) *out_column = c >= 0 ? c : -1;
     if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
     if (c >= 0) e->st_emitted = c + 1;
+    return EMSPEC_OK;
+}
+
+
+// ---- streaming by sample blocks (per-stream sample ring + pending-column ring) ----
+namespace {
+constexpr int kPushFrames = 64;   // frames per launch in sample mode; the ring holds 2D + kPushFrames columns
+
+// frames completed once `total` samples of the stream have been seen
+int64_t frames_after(int64_t total, int n, int hop) { return total >= n ? (total - n) / hop + 1 : 0; }
+}  // namespace
+
+int64_t emspec_push_columns(const emspec_engine* e, int64_t count, int32_t n, int32_t hop, int32_t reassign) {
+    if (!e || count < 0 || !supported_fft(n) || hop < 1 || hop > n) return -1;
+    const int D = latency(n, hop, reassign ? 1 : 0);
+    const bool live = e->st_mode == 2;
+    const int64_t fed = live ? e->st_fed : 0;
+    const int64_t seen = live ? e->st_fed * (int64_t)hop + e->st_have : 0;
+    const int64_t after = frames_after(seen + count, n, hop);
+    const int64_t before_cols = fed > D ? fed - D : 0, after_cols = after > D ? after - D : 0;
+    return after_cols - before_cols;
+}
+
+int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, int32_t n, int32_t hop, int32_t reassign,
+                        float* out_db, uint8_t* out_rgba, int32_t rows, int64_t max_columns, int64_t* out_count,
+                        int64_t* out_first_column) {
+    if (!e || (!samples && count > 0) || count < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
+    reassign = reassign ? 1 : 0;
+    if (e->st_reassign >= 0 && (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 2))
+        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
+    const int64_t expect = emspec_push_columns(e, count, n, hop, reassign);
+    if ((out_db || out_rgba) && expect > max_columns)
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "output holds fewer columns than this block completes (" +
+                                                   std::to_string(expect) + "); size it with emspec_push_columns()");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int R = e->cfg.rows;
+    const size_t cap = (size_t)n + (size_t)(kPushFrames - 1) * hop;   // samples one launch can see
+    if (e->st_reassign < 0) {
+        const int D = latency(n, hop, reassign);
+        const int W = 2 * D + kPushFrames;
+        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
+        for (int b = 0; b < 2; ++b)
+            if ((rc = grow(e, (void**)&e->d_sbuf[b], &e->sbuf_bytes[b], cap * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_pushdb, &e->pushdb_bytes, (size_t)kPushFrames * R * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_pushrgba, &e->pushrgba_bytes, (size_t)kPushFrames * R * 4))) return rc;
+        if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
+        if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
+        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
+        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W; e->st_mode = 2;
+        e->st_have = 0; e->st_cur = 0;
+    }
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const PlanDev pd = plan_dev(e, *p, hop, reassign);
+    const DbMap m = db_map(e, n);
+    const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
+    if (post && !e->d_pstate) {
+        HIPCHK(e, hipMalloc(&e->d_pstate, (size_t)(4096 + 4) * 4));
+        HIPCHK(e, hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream));
+    }
+    const int D = e->st_D, W = e->st_W;
+    int64_t produced = 0, first = -1, used = 0;
+    while (used < count) {
+        const int64_t take = std::min<int64_t>(count - used, (int64_t)cap - e->st_have);
+        float* buf = e->d_sbuf[e->st_cur];
+        HIPCHK(e, hipMemcpyAsync(buf + e->st_have, samples + used, (size_t)take * 4, hipMemcpyHostToDevice, e->stream));
+        used += take;
+        e->st_have += take;
+        const int64_t M = frames_after(e->st_have, n, hop);   // <= kPushFrames by the size of the buffer
+        if (M == 0) continue;
+        const int64_t j0 = e->st_fed;
+        FrameSinks sk;
+        sk.hist = e->d_ring;
+        sk.hist_slots = W;
+        sk.total_cols = INT64_MAX;
+        sk.ring = 1;
+        sk.col_offset = j0;   // buffered sample 0 is the first sample of absolute frame j0
+        HIPCHK(e, launch_frames(n, pd, buf, e->st_have, 1, 0, M, sk, e->stream));
+        // frames j0..j0+M-1 complete columns j0-D .. j0+M-1-D
+        const int64_t c0 = std::max<int64_t>(j0 - D, 0), c1 = j0 + M - D;   // [c0, c1)
+        for (int64_t c = c0; c < c1;) {
+            const int64_t slot = c % W;
+            const int64_t run = std::min<int64_t>(c1 - c, W - slot);        // contiguous slots before the ring wraps
+            float* cells = e->d_ring + (size_t)slot * R;
+            float* ddb = e->d_pushdb + (size_t)(c - c0) * R;
+            uint8_t* drg = e->d_pushrgba + (size_t)(c - c0) * R * 4;
+            HIPCHK(e, launch_finalize(cells, run * R, m, e->d_lut, (out_db || post) ? ddb : nullptr,
+                                      (out_rgba && !post) ? drg : nullptr, nullptr, e->stream));
+            HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)run * R * 4, e->stream));
+            c += run;
+        }
+        const int64_t nc = c1 > c0 ? c1 - c0 : 0;
+        if (post)
+            for (int64_t i = 0; i < nc; ++i)   // AGC and smoothing carry state from column to column
+                HIPCHK(e, launch_post_column(e->d_pushdb + (size_t)i * R, R, e->smoothing, e->agc, e->cfg.db_top, m, e->d_lut,
+                                             out_rgba ? e->d_pushrgba + (size_t)i * R * 4 : nullptr, e->d_pstate,
+                                             e->d_pstate + 4, e->stream));
+        if (nc > 0) {
+            if (first < 0) first = c0;
+            if (out_db) HIPCHK(e, hipMemcpyAsync(out_db + (size_t)produced * R, e->d_pushdb, (size_t)nc * R * 4, hipMemcpyDeviceToHost, e->stream));
+            if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba + (size_t)produced * R * 4, e->d_pushrgba, (size_t)nc * R * 4, hipMemcpyDeviceToHost, e->stream));
+            produced += nc;
+            e->st_emitted = c1;
+        }
+        // keep the samples later frames still need: everything from the start of frame j0+M
+        const int64_t keep = e->st_have - M * hop;
+        float* other = e->d_sbuf[e->st_cur ^ 1];
+        if (keep > 0) HIPCHK(e, hipMemcpyAsync(other, buf + M * hop, (size_t)keep * 4, hipMemcpyDeviceToDevice, e->stream));
+        e->st_cur ^= 1;
+        e->st_have = keep;
+        e->st_fed = j0 + M;
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (out_count) *out_count = produced;
+    if (out_first_column) *out_first_column = first;
     return EMSPEC_OK;
 }
 

@@ -24,6 +24,7 @@ SYMBOLS = [
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
     "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
     "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free", "emspec_set_display",
+    "emspec_push_samples", "emspec_push_columns",
 ]
 
 
@@ -70,6 +71,10 @@ def load():
     lib.emspec_column.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_int32, C.POINTER(C.c_int64)]
     lib.emspec_column_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]
+    lib.emspec_push_columns.restype = C.c_int64
+    lib.emspec_push_columns.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    lib.emspec_push_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.emspec_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(Out)]
     lib.emspec_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
@@ -263,6 +268,21 @@ class Engine:
         self._chk(self._lib.emspec_column(self._h, _np_ptr(frame), n, hop, int(bool(reassign)), _np_ptr(db),
                                           _np_ptr(rgba), self.rows, C.byref(c)))
         return (db, rgba, int(c.value)) if want_rgba else (db, int(c.value))
+
+    def push_samples(self, samples, n, hop, reassign=True, want_rgba=False):
+        """Feed a block of samples of any length; returns (db [k][rows], first_column) (+ rgba) for the k columns
+        the block completed (k may be 0)."""
+        samples = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        k = int(self._lib.emspec_push_columns(self._h, samples.size, n, hop, int(bool(reassign))))
+        if k < 0:
+            raise EmspecError(ERR_INVALID_ARG, "invalid fft size / hop")
+        db = np.empty((k, self.rows), np.float32)
+        rgba = np.empty((k, self.rows, 4), np.uint8) if want_rgba else None
+        cnt, first = C.c_int64(-1), C.c_int64(-2)
+        self._chk(self._lib.emspec_push_samples(self._h, _np_ptr(samples), samples.size, n, hop, int(bool(reassign)),
+                                                _np_ptr(db), _np_ptr(rgba), self.rows, k, C.byref(cnt), C.byref(first)))
+        assert cnt.value == k
+        return (db, rgba, int(first.value)) if want_rgba else (db, int(first.value))
 
     def flush(self, want_rgba=False):
         db = np.empty(self.rows, np.float32)

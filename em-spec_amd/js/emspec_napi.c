@@ -186,6 +186,54 @@ static napi_value Flush(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* pushColumns(handle, count, fftSize, hop, reassign) -> columns a block of `count` samples will complete */
+static napi_value PushColumns(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 5) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pushColumns(handle, count, fftSize, hop, reassign)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    int64_t count; int32_t n, hop; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[1], &count));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[4], &argv[4]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[4], &reassign));
+    const int64_t k = emspec_push_columns(h->e, count, n, hop, reassign ? 1 : 0);
+    if (k < 0) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "invalid count / fftSize / hop"); return NULL; }
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, k, &r));
+    return r;
+}
+
+/* push(handle, samples:Float32Array, fftSize, hop, reassign, rows, outDb?:Float32Array(k*rows), outRgba?:Uint8Array(4*k*rows))
+ * -> absolute index of the first completed column (-1 when the block completed none) */
+static napi_value Push(napi_env env, napi_callback_info info) {
+    size_t argc = 8; napi_value argv[8];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 6) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "push(handle, samples, fftSize, hop, reassign, rows[, outDb, outRgba])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* smp; size_t slen;
+    if (!get_typed(env, argv[1], napi_float32_array, &smp, &slen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "samples must be a Float32Array"); return NULL; }
+    int32_t n, hop, rows; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[4], &argv[4]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[4], &reassign));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &rows));
+    if (rows < 1) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "rows must be positive"); return NULL; }
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0;
+    if (argc > 6 && !get_typed(env, argv[6], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 7 && !get_typed(env, argv[7], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    int64_t room = INT64_MAX;   /* columns the smaller output can hold */
+    if (db) room = (int64_t)(dblen / (size_t)rows);
+    if (rgba && (int64_t)(rgbalen / (4 * (size_t)rows)) < room) room = (int64_t)(rgbalen / (4 * (size_t)rows));
+    int64_t count = 0, first = -1;
+    int rc = emspec_push_samples(h->e, (const float*)smp, (int64_t)slen, n, hop, reassign ? 1 : 0, (float*)db, (uint8_t*)rgba,
+                                 rows, room, &count, &first);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, first, &r));
+    return r;
+}
+
 static napi_value Reset(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -414,6 +462,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"rows", NULL, Rows, NULL, NULL, NULL, napi_default, NULL},
         {"column", NULL, Column, NULL, NULL, NULL, napi_default, NULL},
         {"flush", NULL, Flush, NULL, NULL, NULL, napi_default, NULL},
+        {"push", NULL, Push, NULL, NULL, NULL, napi_default, NULL},
+        {"pushColumns", NULL, PushColumns, NULL, NULL, NULL, napi_default, NULL},
         {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},

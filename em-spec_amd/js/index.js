@@ -33,6 +33,21 @@ class Engine {
     return out;
   }
 
+  /**
+   * Streaming by sample blocks (what an audio callback delivers): feed any number of new samples; every
+   * `hop` of them completes a frame.  Returns { first, count, db, rgba }: `count` finished columns,
+   * oldest first, `first` = absolute index of the first (-1 when count is 0), db = Float32Array(count*rows),
+   * rgba = Uint8Array(4*count*rows) when wantRgba.  Drain the last D columns with flush().
+   */
+  pushSamples(samples, fftSize, hop, reassign = true, wantRgba = false) {
+    const count = native.pushColumns(this._h, samples.length, fftSize, hop, !!reassign);
+    const db = new Float32Array(count * this.rows);
+    const rgba = wantRgba ? new Uint8Array(4 * count * this.rows) : undefined;
+    const first = native.push(this._h, samples, fftSize, hop, !!reassign, this.rows, db, rgba);
+    if (count > 0) this.lastColumn = first + count - 1;
+    return { first, count, db, rgba };
+  }
+
   /** Emit one of the columns still pending after the last frame; throws EMSPEC_ERR_STATE when none. */
   flush(outRgba = undefined) {
     const out = new Float32Array(this.rows);

@@ -46,6 +46,39 @@ function check(fftSize, hop, reassign, frames) {
   return worst;
 }
 
+/* sample-block streaming: uneven blocks (an audio callback's sizes) must give the batch columns */
+function checkPush(fftSize, hop, reassign, frames) {
+  const eng = em.createEngine({});
+  const L = fftSize + hop * (frames - 1) + 77;     // a ragged tail that completes no frame
+  const pcm = synth(L);
+  const R = eng.rows;
+  const ref = new Float32Array(frames * R);
+  eng.computeColumns(pcm, 1, L, fftSize, hop, reassign, { db: ref });
+  const got = new Float32Array(frames * R);
+  const sizes = [1, 300, 4096, 17, 2048, 20000, 5];
+  let pos = 0, next = 0, i = 0;
+  while (pos < L) {
+    const len = Math.min(sizes[i++ % sizes.length], L - pos);
+    const r = eng.pushSamples(pcm.subarray(pos, pos + len), fftSize, hop, reassign);
+    pos += len;
+    if (r.count > 0) {
+      if (r.first !== next) throw new Error('push: first column ' + r.first + ' expected ' + next);
+      got.set(r.db, next * R); next += r.count;
+    } else if (r.first !== -1) throw new Error('push: empty block must report -1');
+  }
+  const D = em.latencyColumns(fftSize, hop, reassign);
+  if (next !== frames - D) throw new Error('push: columns before flush ' + next);
+  for (let k = 0; k < D; k++) { const col = eng.flush(); got.set(col, eng.lastColumn * R); }
+  let worst = 0;
+  for (let k = 0; k < got.length; k++) worst = Math.max(worst, Math.abs(got[k] - ref[k]));
+  if (!(worst < 8.7e-4)) throw new Error('pushSamples vs batch dB mismatch ' + worst);
+  let threw = false;
+  try { eng.computeSpectrogramColumn(pcm.subarray(0, fftSize), fftSize, hop, reassign); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
+  if (!threw) throw new Error('mixing frame and sample feeding must throw EMSPEC_ERR_STATE');
+  eng.destroy();
+  return worst;
+}
+
 async function checkAsync() {
   const eng = em.createEngine({});
   const fftSize = 4096, hop = 256, frames = 24, L = fftSize + hop * (frames - 1);
@@ -82,6 +115,8 @@ async function checkAsync() {
 
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);
+checkPush(4096, 256, true, 150);
+checkPush(1024, 256, false, 90);
 const col = em.computeSpectrogramColumn(new Float32Array(1024), 1024, 256, false);
 if (col.length !== 1024) throw new Error('module-level call');
 checkAsync().then(() => {

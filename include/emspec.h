@@ -150,6 +150,29 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop,
 int emspec_column_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba,
                         int32_t rows, int64_t* out_column);
 
+/*
+ * Streaming by sample blocks: the audio callback hands over whatever block it
+ * has (any count >= 0); the engine keeps the unconsumed tail of the stream on
+ * the device (sample ring) next to the pending-column ring, and every `hop`
+ * new samples complete one frame.  Finished columns (column c is complete once
+ * frame c+D has been seen) are written oldest first to out_db [max_columns][rows]
+ * and/or out_rgba [max_columns][rows][4]; *out_count receives how many,
+ * *out_first_column the absolute index of the first (-1 if none).  Unlike
+ * emspec_column no empty columns are produced while the ring primes.
+ * emspec_push_columns() tells in advance how many columns a block of `count`
+ * samples will complete (for sizing the outputs; -1 on invalid arguments); a
+ * block that completes more than max_columns is rejected before any state changes.
+ * The D columns pending after the last block are drained with emspec_column_flush;
+ * samples short of a hop are dropped by emspec_reset.  One stream must be fed
+ * through either emspec_column or emspec_push_samples, not both (EMSPEC_ERR_STATE).
+ */
+int64_t emspec_push_columns(const emspec_engine* e, int64_t count, int32_t n,
+                            int32_t hop, int32_t reassign);
+int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count,
+                        int32_t n, int32_t hop, int32_t reassign, float* out_db,
+                        uint8_t* out_rgba, int32_t rows, int64_t max_columns,
+                        int64_t* out_count, int64_t* out_first_column);
+
 /* Drop all per-stream state (sample position, pending ring). */
 int emspec_reset(emspec_engine* e);
 

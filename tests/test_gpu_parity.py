@@ -469,3 +469,63 @@ def test_dump_vs_hipfft_three_window(engine, n, hop):
     both = valid & (row[0] >= 0)
     assert np.mean(row[0][both] != hrow[both]) < 2e-3
     assert np.mean(col[0][both] != hcol[both]) < 2e-3
+
+
+@pytest.mark.parametrize("n,hop,reassign", [(4096, 256, True), (1024, 256, False), (2048, 2048, True), (16384, 512, True),
+                                            (512, 1, True)])
+def test_sample_block_streaming_equals_batch(engine, n, hop, reassign):
+    """blocks of arbitrary length through emspec_push_samples (device sample
+    ring + pending-column ring, up to 64 frames per launch) give the batch columns."""
+    frames = 300 if hop == 1 else 150 if n <= 4096 else 70
+    rng = np.random.default_rng(n + hop)
+    L = n + hop * (frames - 1) + min(hop - 1, 77)
+    pcm = synth.streams(1, L)[0]
+    out = engine.batch(pcm[None], n, hop, reassign, want=("db", "rgba"))
+    ref, ref_rgba = out["db"][0], out["rgba"][0]
+    engine.reset()
+    import emspec
+    D = emspec.latency_columns(n, hop, reassign)
+    cols, rg, pos, nxt = [], [], 0, 0
+    while pos < L:
+        ln = int(min(rng.choice([1, 3, hop, hop + 1, n, 3 * n + 5, 70 * hop]), L - pos))
+        db, rgba, first = engine.push_samples(pcm[pos:pos + ln], n, hop, reassign, want_rgba=True)
+        pos += ln
+        if len(db):
+            assert first == nxt
+            cols.append(db); rg.append(rgba); nxt += len(db)
+        else:
+            assert first == -1
+    assert nxt == frames - D
+    for _ in range(D):
+        db, rgba, c = engine.flush(want_rgba=True)
+        assert c == nxt
+        cols.append(db[None]); rg.append(rgba[None]); nxt += 1
+    with pytest.raises(Exception):
+        engine.flush()
+    with pytest.raises(Exception):   # one stream, one feeding mode
+        engine.column(pcm[:n], hop, reassign)
+    engine.reset()
+    got = np.concatenate(cols)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < 8.7e-4
+    # colours can differ by one palette step where the dB value sits on a step edge
+    assert np.mean(np.concatenate(rg) != ref_rgba) < 1e-3
+
+
+def test_sample_block_streaming_rejects_small_output(engine):
+    import ctypes as C
+    import emspec
+    lib = emspec.load()
+    engine.reset()
+    x = np.zeros(4096 + 256 * 40, np.float32)
+    need = lib.emspec_push_columns(engine._h, x.size, 4096, 256, 1)
+    assert need == 41 - 8
+    db = np.empty((need - 1, engine.rows), np.float32)
+    cnt, first = C.c_int64(), C.c_int64()
+    rc = lib.emspec_push_samples(engine._h, C.c_void_p(x.ctypes.data), x.size, 4096, 256, 1, C.c_void_p(db.ctypes.data),
+                                 None, engine.rows, need - 1, C.byref(cnt), C.byref(first))
+    assert rc == emspec.ERR_INVALID_ARG
+    # nothing was consumed: the same block still completes `need` columns
+    assert lib.emspec_push_columns(engine._h, x.size, 4096, 256, 1) == need
+    assert lib.emspec_push_columns(engine._h, 10, 3000, 256, 1) == -1
+    engine.reset()

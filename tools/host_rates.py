@@ -36,3 +36,16 @@ for j in range(20, 520):
 dt = (time.perf_counter() - t0) / 500
 print(f"emspec_column (streaming, one frame per call: H2D + 2 kernels + D2H + sync): {dt * 1e6:.1f} us per column "
       f"= {1 / dt:.0f} columns/s per engine (real time needs 187.5/s per stream)")
+for blk in (512, 2048, 16384, 131072):
+    e.reset()
+    e.push_samples(fr[:n + 16 * hop], n, hop, True)
+    pos, cols = n + 16 * hop, 0
+    t0 = time.perf_counter()
+    while pos + blk <= min(fr.size, n + 16 * hop + 400 * blk):
+        db, _ = e.push_samples(fr[pos:pos + blk], n, hop, True)
+        cols += len(db)
+        pos += blk
+    dt = time.perf_counter() - t0
+    print(f"emspec_push_samples (streaming, blocks of {blk} samples = {blk // hop} columns per call): "
+          f"{dt / max(cols, 1) * 1e6:.1f} us per column = {cols / dt:.3e} columns/s per engine")
+e.reset()
