@@ -196,7 +196,9 @@ void emspec_host_free(void* p);
  * Same, device-resident: pcm and the outputs are device pointers on the
  * engine's device; the kernels are enqueued on hip_stream (a hipStream_t
  * passed as void*, NULL = the HIP default stream) and the call returns
- * without synchronising.  Output pointers may be NULL.
+ * without synchronising.  Output pointers may be NULL.  Calls on one engine
+ * share its device workspaces: enqueue them on one stream, or order them
+ * yourself (events) when using several.
  */
 int emspec_batch_device(emspec_engine* e, const float* pcm_dev, int32_t S,
                         int64_t L, int32_t n, int32_t hop, int32_t reassign,
