@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n1024"])
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--log2-samples", type=int, default=22)
-    ap.add_argument("--chunks", type=int, default=8, help="stream-chunks per step (gather overlap, N>1)")
+    ap.add_argument("--chunks", type=int, default=2, help="stream-chunks per step (gather overlap, N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-chunks", type=int, default=0, help="N=1: launch per stream-chunk as the N>1 path does (no gather)")
     ap.add_argument("--reassign", type=int, default=1)

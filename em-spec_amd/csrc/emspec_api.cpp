@@ -403,6 +403,16 @@ int emspec_debug_fused_error(emspec_engine* e) {
     return fused_read_errflag();
 }
 
+
+// Diagnostic: enqueue a kernel that keeps `groups` workgroups resident for ~usec microseconds on hip_stream.
+int emspec_debug_occupy(emspec_engine* e, int32_t groups, int32_t usec, void* hip_stream) {
+    if (!e || groups < 1 || groups > 4096 || usec < 1 || usec > 2000000) return fail(e, EMSPEC_ERR_INVALID_ARG, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
+    HIPCHK(e, launch_occupy(groups, usec, reinterpret_cast<unsigned*>(e->d_coldb), (hipStream_t)hip_stream));
+    return EMSPEC_OK;
+}
+
 // Diagnostic (tests only): evaluate the fused kernels' hinted row lookup and the generic
 // binary search on `count` host values of k-hat for fft size n.
 int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_t count, int32_t* out_hint,

@@ -489,6 +489,24 @@ hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh,
     return hipGetLastError();
 }
 
+// Diagnostic: hold `groups` workgroups of 256 threads on the device for about `usec` microseconds
+// (constant 100 MHz wall clock; the iteration cap bounds the spin whatever the clock does).  Stands in
+// for a communication kernel that occupies compute units beside the column kernels.
+__global__ void occupy_kernel(long long ticks, unsigned* sink) {
+    const long long t0 = wall_clock64();
+    unsigned n = 0;
+    for (long long it = 0; it < 400000000LL; ++it) {
+        if (wall_clock64() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+        ++n;
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) *sink = n;
+}
+hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
+    hipLaunchKernelGGL(occupy_kernel, dim3(groups), dim3(256), 0, st, (long long)usec * 100, sink);
+    return hipGetLastError();
+}
+
 }  // namespace emspec
 
 #include "fused.hip.inc"

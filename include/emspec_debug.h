@@ -29,6 +29,11 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
  * kernel (EMSPEC_FUSED_VARIANT=r8t) ever timed out: a protocol bug, results are then invalid. */
 int emspec_debug_fused_error(emspec_engine* e);
 
+/* Enqueue on hip_stream a kernel that keeps `groups` 256-thread workgroups resident for about
+ * `usec` microseconds (bounded spin): a stand-in for a communication kernel holding compute
+ * units while the column kernels run on another stream (tools/occupancy_probe.py). */
+int emspec_debug_occupy(emspec_engine* e, int32_t groups, int32_t usec, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
