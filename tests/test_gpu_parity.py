@@ -529,3 +529,31 @@ def test_sample_block_streaming_rejects_small_output(engine):
     assert lib.emspec_push_columns(engine._h, x.size, 4096, 256, 1) == need
     assert lib.emspec_push_columns(engine._h, 10, 3000, 256, 1) == -1
     engine.reset()
+
+
+def test_nan_and_inf_samples_are_contained(engine):
+    """A NaN or Inf sample poisons every bin of the frames that contain it (their power is not a finite
+    number >= the floor, so those bins are dropped) and nothing else: outputs stay finite, frames that do not
+    overlap the bad sample are unaffected, and the oracle agrees."""
+    n, hop, frames = 4096, 256, 60
+    pcm = _pcm(n, hop, frames, S=2)
+    clean = engine.batch(pcm, n, hop, True, want=("db", "index"))
+    bad = pcm.copy()
+    bad[0, 7000] = np.nan
+    bad[1, 9000] = np.inf
+    out = engine.batch(bad, n, hop, True, want=("db", "index"))
+    assert np.isfinite(out["db"]).all()
+    cfg = O.make_cfg(n, hop, True)
+    odb, _, oidx = O.batch_f32(cfg, bad, want=("db", "index"))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    assert np.mean(out["index"] != oidx) < 1e-3
+    for s, pos in ((0, 7000), (1, 9000)):
+        touched = [j for j in range(frames) if j * hop <= pos < j * hop + n]
+        # columns further than D from every poisoned frame equal the clean run (up to the order of the float sums)
+        far = [c for c in range(frames) if all(abs(c - j) > 8 for j in touched)]
+        assert far, "test needs some unaffected columns"
+        assert np.max(np.abs(out["db"][s, far] - clean["db"][s, far])) < 8.7e-4
+        # a column whose own frame and all neighbours within D are poisoned is empty
+        dead = [c for c in range(frames) if all((c + d) in touched for d in range(-8, 9) if 0 <= c + d < frames)]
+        if dead:
+            assert np.all(out["index"][s, dead] == 0)
