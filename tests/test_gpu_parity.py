@@ -103,11 +103,12 @@ def test_streaming_equals_batch(engine):
     assert np.max(np.abs(got - ref)) < 8.7e-4
 
 
+@pytest.mark.parametrize("hop", [256, 512, 1024])
 @pytest.mark.parametrize("frames,S,reassign", [(203, 3, True), (64, 1, True), (5, 2, True), (130, 2, False), (1, 1, True)])
-def test_fused_segments_match_oracle(engine, frames, S, reassign):
-    """Fused LDS-ring kernel (N=4096, hop=256): several segments per stream, odd column counts,
-    fewer columns than the reassignment reach, reassign off."""
-    n, hop = 4096, 256
+def test_fused_segments_match_oracle(engine, frames, S, reassign, hop):
+    """Fused LDS-ring kernel (N=4096; hop 256, 512, 1024): several segments per stream, odd column
+    counts, fewer columns than the reassignment reach, reassign off."""
+    n = 4096
     assert engine.fused(n, hop, reassign)
     pcm = _pcm(n, hop, frames, S=S)
     out = engine.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
@@ -118,6 +119,26 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign):
     d = np.abs(out["index"].astype(int) - oidx.astype(int))
     assert d.max() <= 1 and np.mean(d != 0) < 1e-3
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
+
+
+@pytest.mark.parametrize("hop,seglen", [(512, 66), (512, 250), (1024, 64), (1024, 130)])
+def test_fused_other_hops_short_segments(hop, seglen, monkeypatch):
+    """hop 512 / 1024 builds of the fused kernel with many short segments per stream (segment
+    boundaries recompute a 2D-frame halo; the ring has 10 / 6 slots)."""
+    import emspec
+    monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
+    n, frames, S = 4096, 700, 2
+    pcm = _pcm(n, hop, frames, S=S)
+    eng = emspec.Engine()
+    try:
+        assert eng.fused(n, hop, True)
+        out = eng.batch(pcm, n, hop, True, want=("db", "index"))
+    finally:
+        eng.close()
+    odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
 
 
 def test_hinted_row_lookup_equals_binary_search(engine):
