@@ -103,12 +103,11 @@ def test_streaming_equals_batch(engine):
     assert np.max(np.abs(got - ref)) < 8.7e-4
 
 
-@pytest.mark.parametrize("hop", [256, 512, 1024])
+@pytest.mark.parametrize("n,hop", [(4096, 256), (4096, 512), (4096, 1024), (8192, 512), (8192, 1024)])
 @pytest.mark.parametrize("frames,S,reassign", [(203, 3, True), (64, 1, True), (5, 2, True), (130, 2, False), (1, 1, True)])
-def test_fused_segments_match_oracle(engine, frames, S, reassign, hop):
-    """Fused LDS-ring kernel (N=4096; hop 256, 512, 1024): several segments per stream, odd column
-    counts, fewer columns than the reassignment reach, reassign off."""
-    n = 4096
+def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
+    """Fused LDS-ring kernels (N=4096 at hop 256/512/1024, N=8192 at hop 512/1024): several segments
+    per stream, odd column counts, fewer columns than the reassignment reach, reassign off."""
     assert engine.fused(n, hop, reassign)
     pcm = _pcm(n, hop, frames, S=S)
     out = engine.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
@@ -121,13 +120,14 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign, hop):
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
 
 
-@pytest.mark.parametrize("hop,seglen", [(512, 66), (512, 250), (1024, 64), (1024, 130)])
-def test_fused_other_hops_short_segments(hop, seglen, monkeypatch):
-    """hop 512 / 1024 builds of the fused kernel with many short segments per stream (segment
-    boundaries recompute a 2D-frame halo; the ring has 10 / 6 slots)."""
+@pytest.mark.parametrize("n,hop,seglen", [(4096, 512, 66), (4096, 512, 250), (4096, 1024, 64), (4096, 1024, 130),
+                                          (8192, 512, 65), (8192, 512, 131), (8192, 1024, 64), (8192, 1024, 99)])
+def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
+    """The other builds of the fused kernels with many short segments per stream (segment boundaries
+    recompute a 2D-frame halo; odd segment lengths; smaller rings)."""
     import emspec
     monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
-    n, frames, S = 4096, 700, 2
+    frames, S = (700 if n == 4096 else 400), 2
     pcm = _pcm(n, hop, frames, S=S)
     eng = emspec.Engine()
     try:
