@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n1024"])
+    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n8192", "n1024"])
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--log2-samples", type=int, default=22)
     ap.add_argument("--chunks", type=int, default=2, help="stream-chunks per step (gather overlap, N>1)")
@@ -133,6 +133,8 @@ def main():
     from emspec import shard
     if args.workload == "n16384":
         n, hop = 16384, 512
+    elif args.workload == "n8192":
+        n, hop = 8192, 512
     elif args.workload == "n1024":
         n, hop = 1024, 256
     else:
