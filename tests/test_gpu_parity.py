@@ -103,7 +103,9 @@ def test_streaming_equals_batch(engine):
     assert np.max(np.abs(got - ref)) < 8.7e-4
 
 
-@pytest.mark.parametrize("n,hop", [(4096, 256), (4096, 512), (4096, 1024), (8192, 512), (8192, 1024)])
+@pytest.mark.parametrize("n,hop", [(4096, 256), (4096, 512), (4096, 1024), (8192, 512), (8192, 1024),
+                                   (2048, 128), (2048, 256), (2048, 200), (2048, 2048), (1024, 256), (1024, 128), (1024, 100),
+                                   (1024, 1024)])
 @pytest.mark.parametrize("frames,S,reassign", [(203, 3, True), (64, 1, True), (5, 2, True), (130, 2, False), (1, 1, True)])
 def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
     """Fused LDS-ring kernels (N=4096 at hop 256/512/1024, N=8192 at hop 512/1024): several segments
@@ -121,13 +123,15 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
 
 
 @pytest.mark.parametrize("n,hop,seglen", [(4096, 512, 66), (4096, 512, 250), (4096, 1024, 64), (4096, 1024, 130),
-                                          (8192, 512, 65), (8192, 512, 131), (8192, 1024, 64), (8192, 1024, 99)])
+                                          (8192, 512, 65), (8192, 512, 131), (8192, 1024, 64), (8192, 1024, 99),
+                                          (2048, 128, 67), (2048, 256, 130), (2048, 777, 64), (1024, 256, 65), (1024, 128, 101),
+                                          (1024, 333, 64)])
 def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
     """The other builds of the fused kernels with many short segments per stream (segment boundaries
     recompute a 2D-frame halo; odd segment lengths; smaller rings)."""
     import emspec
     monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
-    frames, S = (700 if n == 4096 else 400), 2
+    frames, S = (400 if n == 8192 else 700), 2
     pcm = _pcm(n, hop, frames, S=S)
     eng = emspec.Engine()
     try:
