@@ -105,7 +105,7 @@ def test_streaming_equals_batch(engine):
 
 @pytest.mark.parametrize("n,hop", [(4096, 256), (4096, 512), (4096, 1024), (8192, 512), (8192, 1024),
                                    (2048, 128), (2048, 256), (2048, 200), (2048, 2048), (1024, 256), (1024, 128), (1024, 100),
-                                   (1024, 1024)])
+                                   (1024, 1024), (4096, 230), (4096, 300), (4096, 2048), (4096, 4096)])
 @pytest.mark.parametrize("frames,S,reassign", [(203, 3, True), (64, 1, True), (5, 2, True), (130, 2, False), (1, 1, True)])
 def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
     """Fused LDS-ring kernels (N=4096 at hop 256/512/1024, N=8192 at hop 512/1024): several segments
@@ -125,7 +125,7 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
 @pytest.mark.parametrize("n,hop,seglen", [(4096, 512, 66), (4096, 512, 250), (4096, 1024, 64), (4096, 1024, 130),
                                           (8192, 512, 65), (8192, 512, 131), (8192, 1024, 64), (8192, 1024, 99),
                                           (2048, 128, 67), (2048, 256, 130), (2048, 777, 64), (1024, 256, 65), (1024, 128, 101),
-                                          (1024, 333, 64)])
+                                          (1024, 333, 64), (4096, 384, 70), (4096, 3000, 64)])
 def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
     """The other builds of the fused kernels with many short segments per stream (segment boundaries
     recompute a 2D-frame halo; odd segment lengths; smaller rings)."""
