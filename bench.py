@@ -225,6 +225,22 @@ def main():
                     break
                 except Exception:
                     pass
+        # second view of the same launch: VALU issue rate against the chip's measured rate.  The instruction
+        # count per launch comes from the committed SQ counters, the chip rate from tools/ubench/valu_rate.hip.
+        valu = None
+        if traffic is not None:
+            try:
+                tag = os.path.basename(traffic_src).split("_")[0]
+                for ln in open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.txt")):
+                    if ln.startswith("SQ_INSTS_VALU"):
+                        insts = float(ln.split()[1])
+                        rate = insts / (k_avg_ms * 1e-3) / 1024          # per SIMD (256 CUs x 4)
+                        valu = {"valu_insts_per_launch": insts, "achieved_per_simd_per_s": rate,
+                                "chip_measured_per_simd_per_s": {"v_fma_f32": 7.4e8, "v_add_f32": 8.7e8},
+                                "frac_range": [rate / 8.7e8, rate / 7.4e8],
+                                "source": f"profiles/{tag}_sq_counters.txt, profiles/{tag}_valu_rate.txt"}
+            except Exception:
+                valu = None
         line = {
             "metric": "reassigned spectrogram columns/sec (4096-pt, hop 256, 48 kHz)" if n == 4096 else
                       f"reassigned spectrogram columns/sec ({n}-pt, hop {hop}, 48 kHz)",
@@ -244,6 +260,8 @@ def main():
                          "note": "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / "
                                  "HIP-event duration of the column kernel(s) on the launch stream; PMC traffic: profiles/"},
         }
+        if valu is not None:
+            line["valu_issue"] = valu
         if world == 1 and args.workload == "batch64":
             # BASELINE configs[1] (one stream of 2^22 samples) measured beside the headline, same engine
             one = pcm[:1].contiguous()
