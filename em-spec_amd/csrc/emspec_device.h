@@ -160,10 +160,21 @@ struct HintLookup {
         r0 -= (kh < lo) ? 1 : 0;
         return r0;
     }
+    // Row, or -1 / R when kh lies below / at-or-above the table: the +-1 correction of the clamped hint walks
+    // off the table exactly when kh is out of range, so `(unsigned)row < R` replaces the two range compares.
+    // (NaN compares false and would read as in range: callers gate on a finite power first.)
+    __device__ __forceinline__ int row_signed(float kh) const {
+        if (wtop) return in_range(kh) ? row_unchecked(kh) : -1;
+        return row_unchecked(kh);
+    }
     __device__ __forceinline__ int operator()(float kh) const { return in_range(kh) ? row_unchecked(kh) : -1; }
 };
 
 struct BinOut { float power; int dcol; int row; };  // dcol relative to the frame's own column
+
+// (c + c) - s in one instruction: c + c is exact, so fma(2, c, -s) rounds the same real number once, like the
+// two-instruction form of the bit model (oracle: (c + c) - s).  Overflow of c + c aside (|c| > 1.7e38), identical.
+__device__ __forceinline__ float twice_minus(float c, float s) { return __builtin_fmaf(2.0f, c, -s); }
 
 // conjugate split, scaled by 2:  Y = Z[k] + conj Z[N-k],  T = -j (Z[k] - conj Z[N-k])
 struct YT { float yr, yi, tr, ti; };
