@@ -582,3 +582,24 @@ def test_nan_and_inf_samples_are_contained(engine):
         dead = [c for c in range(frames) if all((c + d) in touched for d in range(-8, 9) if 0 <= c + d < frames)]
         if dead:
             assert np.all(out["index"][s, dead] == 0)
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 control flow (stream sharding, chunked + double-buffered gather, max-over-ranks timing)
+    rehearsed with two ranks on this one GPU: gloo carries the gather through host tensors, everything else is
+    the code the 8-GPU run executes."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--streams", "6", "--log2-samples", "18", "--chunks", "3", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints ONE json line
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["steps"] == 3
+    C = (2 ** 18 - 4096) // 256 + 1
+    assert b["config"]["columns_per_step"] == 2 * 6 * C
+    assert b["value"] > 0 and b["cpu_baseline"] is None
