@@ -193,6 +193,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if world > 1:
+        # open the point-to-point connections the gather uses before anything is timed (with --warmup 0 the
+        # first gather would otherwise pay for them inside the timed region)
+        probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
+        shard.gather_columns_into(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
     for _ in range(args.warmup):
         step()
     barrier()
