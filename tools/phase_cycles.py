@@ -31,7 +31,7 @@ assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(),
 torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
-names = ["passA+write", "barrier wait", "passB r/c/w", "passC r/c", "natural write", "bins+scatter", "finalize+shift", "-"]
+names = ["passA+write", "barrier wait", "finalize+passB", "passC r/c", "passD in place", "bins+scatter+A", "loop tail", "-"]
 tot = cyc.sum(axis=2).astype(np.float64)
 print(f"groups {groups.value}; mean cycles per wave {tot.mean():.0f} (readcyclecounter units)")
 for i, nm in enumerate(names[:7]):
