@@ -230,8 +230,10 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
  * interleaved).  Either pointer may be NULL.  For table-parity tests. */
 int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twiddle);
 
-/* 1 if emspec_batch/_device would run the fused LDS-ring kernel for this
- * shape, 0 if the generic two-kernel path (global-atomic histogram). */
+/* 1 if emspec_batch/_device would run a fused LDS-ring kernel for this shape
+ * (n = 1024, 2048, 4096 at any hop whose column ring fits in LDS; n = 8192 at
+ * hop 512 or 1024; at most 1024 rows), 0 if the generic two-kernel path
+ * (per-bin records + LDS tile scatter).  Same results either way. */
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign);
 
 /* Name of the device the engine runs on, e.g. "gfx950". */
