@@ -97,3 +97,27 @@ def test_node_addon_loads_and_reports_errors():
                "try{m.createEngine({});process.exit(6);}catch(e){if(e.code!=='EMSPEC_ERR_NO_DEVICE')process.exit(7);}"))
     r = subprocess.run(["node", "-e", code], cwd=js, capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
+
+
+def test_flagship_kernels_do_not_spill():
+    """The fused kernels run 16 waves per CU on exactly 128 VGPRs each; spilled registers are reloaded serially
+    behind vmcnt and once cost 2x (DESIGN.md §8).  Parse the code-object metadata of a fresh device-only compile;
+    up to two spilled dwords are tolerated (today: one, in the once-per-workgroup prologue of the hop-256 build)."""
+    import re, shutil, subprocess
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "em-spec_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "asm"])
+    text = open(os.path.join(csrc, "kernels.s")).read()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n", text):
+        name = m.group(1)
+        if not any(k in name for k in ("fused4096_r8_kernelILi256ELb0", "fused4096_r8_kernelILi512ELb0", "fused8192_kernel",
+                                       "fused_small_kernel")):
+            continue
+        blk = text[m.start() - 400:m.start() + 1600]
+        meta = dict(re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk))
+        assert int(meta["vgpr_spill_count"]) <= 2 and int(meta["private_segment_fixed_size"]) <= 16, (name, meta)
+        assert int(meta["vgpr_count"]) <= 128, (name, meta)
+        seen += 1
+    assert seen >= 6, seen
