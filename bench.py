@@ -28,14 +28,36 @@ import torch
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _lsr(z, k):
+    """logical right shift of int64 tensors (torch's >> is arithmetic)"""
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def _splitmix64(seed, idx):
+    """draws number idx (int64 tensor, 1-based) of splitmix64 seeded with `seed`: int64 arithmetic wraps mod 2^64"""
+    def s64(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+    z = idx * s64(0x9E3779B97F4A7C15) + s64(seed & ((1 << 64) - 1))
+    z = (z ^ _lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * s64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def _uniform(seed, idx):
+    return _lsr(_splitmix64(seed, idx), 11).double() * (1.0 / (1 << 53))
+
+
 def synth_device(S, L, first_stream, device, fs=48000.0):
-    """Synthetic audio generated on the device (SURVEY.md §8d shape: 8 sinusoids + chirp +
-    noise at -60 dBFS + a click every 24000 samples), float32 in [-1,1]."""
+    """The synthetic audio of SURVEY.md §8(d), generated on the device: the same counter-based definition as
+    em-spec_amd/emspec/synth.py and em-spec_amd/js/synth.js (stream s: seed 1000+s; splitmix64 uniforms; 8
+    sinusoids + chirp + Gaussian noise at -60 dBFS + a click every 24000 samples), float32 in [-1,1]."""
     out = torch.empty((S, L), dtype=torch.float32, device=device)
     t = torch.arange(L, dtype=torch.float64, device=device) / fs
+    half = (L + 1) // 2
+    pair = torch.arange(half, dtype=torch.int64, device=device)
     for s in range(S):
-        g = torch.Generator(device="cpu").manual_seed(1000 + first_stream + s)
-        u = torch.rand(32, generator=g, dtype=torch.float64)
+        seed = 1000 + first_stream + s
+        u = _uniform(seed, torch.arange(1, 65, dtype=torch.int64, device=device)).cpu().numpy()
         x = torch.zeros(L, dtype=torch.float64, device=device)
         for i in range(8):
             f = 30.0 * (20000.0 / 30.0) ** float(u[i])
@@ -45,8 +67,11 @@ def synth_device(S, L, first_stream, device, fs=48000.0):
         rate = 4.0e4 * (0.25 + 0.75 * float(u[25]))
         tt = torch.remainder(t, max(1e-3, min(L / fs, (20000.0 - f0) / rate)))
         x += 0.25 * torch.sin(2 * np.pi * (f0 * tt + 0.5 * rate * tt * tt))
-        gd = torch.Generator(device=device).manual_seed(5000 + first_stream + s)
-        x += 1e-3 * torch.randn(L, generator=gd, dtype=torch.float32, device=device).double()
+        u1 = torch.clamp(_uniform(seed ^ 0x5EED, 64 + 2 * pair + 1), min=1e-300)     # Box-Muller on draws 65, 66, ...
+        u2 = _uniform(seed ^ 0x5EED, 64 + 2 * pair + 2)
+        r = torch.sqrt(-2.0 * torch.log(u1))
+        noise = torch.stack([r * torch.cos(2 * np.pi * u2), r * torch.sin(2 * np.pi * u2)], dim=1).reshape(-1)
+        x += 1e-3 * noise[:L]
         x[::24000] += 1.0
         x /= max(1.0, float(x.abs().max()))
         out[s] = x.float()

@@ -603,3 +603,14 @@ def test_bench_two_rank_rehearsal():
     C = (2 ** 18 - 4096) // 256 + 1
     assert b["config"]["columns_per_step"] == 2 * 6 * C
     assert b["value"] > 0 and b["cpu_baseline"] is None
+
+
+def test_bench_device_synth_matches_definition():
+    """bench.py generates its input on the device from the same counter-based definition as emspec/synth.py."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    got = bench.synth_device(2, 50000, 7, torch.device("cuda", 0)).cpu().numpy()
+    ref = synth.streams(2, 50000, first=7)
+    assert np.max(np.abs(got - ref)) < 1e-6

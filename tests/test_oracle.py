@@ -183,3 +183,23 @@ def test_plain_js_restatement_matches_golden(path, tmp_path):
     assert np.allclose(p, g["power"], rtol=1e-8, atol=1e-16)
     assert np.max(np.abs(khat - g["khat"])) < 1e-5
     assert np.mean(row != g["row"]) < 1e-4 and np.mean(col != g["col"]) < 1e-4
+
+
+def test_js_synthetic_generator_matches_python():
+    """the synthetic input is a counter-based generator defined once and implemented in Python
+    (emspec/synth.py) and JavaScript (js/synth.js); both must produce the same stream."""
+    import json, shutil, subprocess, sys
+    node = shutil.which("node") or shutil.which("nodejs")
+    if not node:
+        pytest.skip("no node")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "em-spec_amd"))
+    from emspec import synth
+    for s, L in ((0, 30000), (41, 5000)):
+        out = subprocess.run([node, os.path.join(root, "em-spec_amd", "js", "synth.js"), str(s), str(L)],
+                             capture_output=True, text=True, check=True, timeout=120).stdout
+        js = np.array(json.loads(out), np.float32)
+        py = synth.stream(s, L)
+        assert js.shape == py.shape
+        assert np.max(np.abs(js - py)) <= 1.2e-7      # sin/log may differ in the last double bit between libms
+        assert np.mean(js != py) < 1e-3
