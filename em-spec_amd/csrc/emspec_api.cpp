@@ -283,6 +283,30 @@ int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t cou
     return EMSPEC_OK;
 }
 
+int emspec_warped_edges_hz(int32_t rows, float fmin_hz, float fmax_hz, float low_end_boost, float freq_scale,
+                           float* out) {
+    if (!out || rows < 1 || !(fmin_hz > 0.0f) || !(fmax_hz > fmin_hz) || !(low_end_boost > 0.0f) || !(freq_scale > 0.0f))
+        return EMSPEC_ERR_INVALID_ARG;
+    const double span = std::log((double)fmax_hz / (double)fmin_hz) / (double)freq_scale;
+    for (int r = 0; r <= rows; ++r)
+        out[r] = (float)((double)fmin_hz * std::exp(span * std::pow((double)r / (double)rows, (double)low_end_boost)));
+    return EMSPEC_OK;
+}
+
+int emspec_make_colormap(float brightness, uint8_t* out) {
+    if (!out || !(brightness >= 0.0f)) return EMSPEC_ERR_INVALID_ARG;
+    static const double stops[5][3] = {{0, 0, 0}, {80, 0, 80}, {200, 50, 50}, {255, 150, 0}, {255, 255, 200}};
+    for (int i = 0; i < 256; ++i) {
+        const double v = std::min(1.0, ((double)i / 255.0) * ((double)brightness / 0.5));
+        const double t = v * 4.0;
+        const int s = std::min(3, (int)std::floor(t));
+        const double f = t - (double)s;
+        for (int c = 0; c < 3; ++c) out[4 * i + c] = (uint8_t)std::floor(stops[s][c] + f * (stops[s + 1][c] - stops[s][c]) + 0.5);
+        out[4 * i + 3] = 255;
+    }
+    return EMSPEC_OK;
+}
+
 int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count) {
     if (!e || !edges_hz) return EMSPEC_ERR_INVALID_ARG;
     if (count != e->cfg.rows + 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "need room for rows+1 edges");

@@ -24,7 +24,7 @@ SYMBOLS = [
     "emspec_batch", "emspec_batch_device", "emspec_parity_dump", "emspec_parity_dump_device",
     "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
     "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free", "emspec_set_display",
-    "emspec_push_samples", "emspec_push_columns",
+    "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
 ]
 
 
@@ -134,6 +134,26 @@ def default_config(**kw):
 
 def num_columns(L, n, hop):
     return int(load().emspec_num_columns(L, n, hop))
+
+
+def warped_edges_hz(rows, fmin_hz, fmax_hz, low_end_boost=1.0, freq_scale=1.0):
+    """rows+1 edges (Hz) of the [BUILD-DEFINED] Frequency Scale / Low-End Boost law, for Engine.set_row_edges_hz."""
+    lib = load()
+    out = np.empty(rows + 1, np.float32)
+    lib.emspec_warped_edges_hz.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    if lib.emspec_warped_edges_hz(rows, fmin_hz, fmax_hz, low_end_boost, freq_scale, _np_ptr(out)) != OK:
+        raise EmspecError(ERR_INVALID_ARG, "invalid axis parameters")
+    return out
+
+
+def make_colormap(brightness=0.5):
+    """The reference ramp scaled by Brightness: uint8 [256][4] for Engine.set_colormap."""
+    lib = load()
+    out = np.empty((256, 4), np.uint8)
+    lib.emspec_make_colormap.argtypes = [C.c_float, C.c_void_p]
+    if lib.emspec_make_colormap(brightness, _np_ptr(out)) != OK:
+        raise EmspecError(ERR_INVALID_ARG, "invalid brightness")
+    return out
 
 
 def latency_columns(n, hop, reassign=True):

@@ -234,6 +234,38 @@ static napi_value Push(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* warpedEdges(rows, fminHz, fmaxHz, lowEndBoost, freqScale) -> Float32Array(rows+1)  (emspec_warped_edges_hz) */
+static napi_value WarpedEdges(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 5) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "warpedEdges(rows, fminHz, fmaxHz, lowEndBoost, freqScale)"); return NULL; }
+    int32_t rows; double a[4];
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[0], &rows));
+    for (int i = 0; i < 4; ++i) NAPI_OK_OR_RETURN(env, napi_get_value_double(env, argv[1 + i], &a[i]));
+    if (rows < 1 || rows > (1 << 20)) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "rows out of range"); return NULL; }
+    napi_value ab, ta; void* data = NULL;
+    NAPI_OK_OR_RETURN(env, napi_create_arraybuffer(env, (size_t)(rows + 1) * 4, &data, &ab));
+    if (emspec_warped_edges_hz(rows, (float)a[0], (float)a[1], (float)a[2], (float)a[3], (float*)data) != EMSPEC_OK) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "need 0 < fminHz < fmaxHz, lowEndBoost > 0, freqScale > 0");
+        return NULL;
+    }
+    NAPI_OK_OR_RETURN(env, napi_create_typedarray(env, napi_float32_array, (size_t)rows + 1, ab, 0, &ta));
+    return ta;
+}
+
+/* referenceColormap(brightness) -> Uint8Array(1024)  (emspec_make_colormap) */
+static napi_value ReferenceColormap(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    double b = 0.5;
+    if (argc >= 1) NAPI_OK_OR_RETURN(env, napi_get_value_double(env, argv[0], &b));
+    napi_value ab, ta; void* data = NULL;
+    NAPI_OK_OR_RETURN(env, napi_create_arraybuffer(env, 1024, &data, &ab));
+    if (emspec_make_colormap((float)b, (uint8_t*)data) != EMSPEC_OK) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "brightness must be >= 0"); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_create_typedarray(env, napi_uint8_array, 1024, ab, 0, &ta));
+    return ta;
+}
+
 static napi_value Reset(napi_env env, napi_callback_info info) {
     size_t argc = 1; napi_value argv[1];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -464,6 +496,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"flush", NULL, Flush, NULL, NULL, NULL, napi_default, NULL},
         {"push", NULL, Push, NULL, NULL, NULL, napi_default, NULL},
         {"pushColumns", NULL, PushColumns, NULL, NULL, NULL, napi_default, NULL},
+        {"warpedEdges", NULL, WarpedEdges, NULL, NULL, NULL, napi_default, NULL},
+        {"referenceColormap", NULL, ReferenceColormap, NULL, NULL, NULL, napi_default, NULL},
         {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},

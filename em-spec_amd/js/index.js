@@ -96,14 +96,12 @@ class Engine {
  * low end more rows.  Returns Float32Array(rows+1) for Engine#setRowEdges.
  */
 function warpedEdges(rows, fminHz, fmaxHz, lowEndBoost = 1, freqScale = 1) {
-  const e = new Float32Array(rows + 1);
-  const span = Math.log(fmaxHz / fminHz) / freqScale;
-  for (let r = 0; r <= rows; r++) e[r] = fminHz * Math.exp(span * Math.pow(r / rows, lowEndBoost));
-  return e;
+  return native.warpedEdges(rows, fminHz, fmaxHz, lowEndBoost, freqScale);   // one implementation for every host: emspec_warped_edges_hz
 }
 
 /** The reference's colour ramp (5-stop gradient measured from its screenshot) with a brightness factor: Uint8Array(1024). */
-function makeColormap(brightness = 0.5, stops = [[0, 0, 0], [80, 0, 80], [200, 50, 50], [255, 150, 0], [255, 255, 200]]) {
+function makeColormap(brightness = 0.5, stops = undefined) {
+  if (stops === undefined) return native.referenceColormap(brightness);   // emspec_make_colormap, shared with the other bindings
   const lut = new Uint8Array(1024);
   const n = stops.length - 1;
   for (let i = 0; i < 256; i++) {

@@ -109,6 +109,19 @@ int emspec_set_colormap(emspec_engine* e, const uint8_t* rgba256x4);
  * frequency read-out needs (README.md:39).  Not allowed while streaming columns are pending.
  */
 int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count);
+
+/*
+ * Display-parameter laws [BUILD-DEFINED] (the reference's slider laws are undocumented,
+ * README.md:44-51), host-independent so that every binding draws the same picture.  No engine needed.
+ * emspec_warped_edges_hz: rows+1 edges for emspec_set_row_edges_hz from "Frequency Scale" (zoom:
+ * the axis spans fmin .. fmin*(fmax/fmin)^(1/freq_scale)) and "Low-End Boost" (row r sits at
+ * u = (r/rows)^low_end_boost along the log range; > 1 gives the low end more rows); (1, 1) is the
+ * plain log axis.  emspec_make_colormap: the reference's 5-stop ramp scaled by
+ * "Brightness" (0.5 = as measured), 256 RGBA entries for emspec_set_colormap.
+ */
+int emspec_warped_edges_hz(int32_t rows, float fmin_hz, float fmax_hz, float low_end_boost,
+                           float freq_scale, float* out_edges_hz);
+int emspec_make_colormap(float brightness, uint8_t* out_rgba256x4);
 int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count);
 
 /*

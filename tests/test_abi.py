@@ -121,3 +121,31 @@ def test_flagship_kernels_do_not_spill():
         assert int(meta["vgpr_count"]) <= 128, (name, meta)
         seen += 1
     assert seen >= 6, seen
+
+
+def test_display_laws_are_shared_by_every_binding():
+    """emspec_warped_edges_hz / emspec_make_colormap: one implementation behind the Python and the JS helpers."""
+    import json
+    import sys
+    import numpy as np
+    e = emspec.warped_edges_hz(1024, 20.0, 24000.0, 1.0, 1.0)
+    r = np.arange(1025) / 1024.0
+    assert np.allclose(e, 20.0 * (24000.0 / 20.0) ** r, rtol=3e-7)            # (1, 1) is the plain log axis
+    w = emspec.warped_edges_hz(512, 30.0, 20000.0, 2.0, 1.5)
+    assert w[0] == np.float32(30.0) and np.all(np.diff(w) > 0)
+    assert abs(w[-1] - 30.0 * (20000.0 / 30.0) ** (1 / 1.5)) < 1e-2
+    assert w[256] < 30.0 * (20000.0 / 30.0) ** (0.5 / 1.5)                      # low-end boost: half the rows end lower
+    with pytest.raises(emspec.EmspecError):
+        emspec.warped_edges_hz(16, 100.0, 50.0)
+    lut = emspec.make_colormap(0.5)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    assert np.array_equal(lut, O.default_lut())                                  # brightness 0.5 = the engine's default palette
+    assert emspec.make_colormap(1.0)[128].tolist() == [255, 255, 200, 255]       # twice as bright: saturates half way
+    node = shutil.which("node") or shutil.which("nodejs")
+    if node and os.path.exists(os.path.join(ROOT, "em-spec_amd", "js", "emspec.node")):
+        js = ("const em=require('%s');process.stdout.write(JSON.stringify({w:Array.from(em.warpedEdges(512,30,20000,2,1.5)),"
+              "c:Array.from(em.makeColormap(0.7))}))" % os.path.join(ROOT, "em-spec_amd", "js", "index.js"))
+        out = json.loads(subprocess.run([node, "-e", js], capture_output=True, text=True, check=True, timeout=60).stdout)
+        assert np.array_equal(np.array(out["w"], np.float32), w)
+        assert np.array_equal(np.array(out["c"], np.uint8).reshape(256, 4), emspec.make_colormap(0.7))
