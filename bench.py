@@ -89,7 +89,7 @@ def cpu_baseline(n, hop, seconds_target=12.0):
     probe = synth.streams(cores, n + hop * 127)
     t0 = time.perf_counter(); O.batch_f32(cfg, probe, want=("db", "index"), threads=cores); dt = time.perf_counter() - t0
     rate = cores * 128 / dt
-    cols_per_stream = int(max(256, min(16384, rate * seconds_target / cores)))
+    cols_per_stream = int(max(256, min(8192, rate * seconds_target / cores)))
     L = n + hop * (cols_per_stream - 1)
     base = synth.streams(1, L)
     pcm = np.stack([np.roll(base[0], 977 * s) for s in range(cores)])
