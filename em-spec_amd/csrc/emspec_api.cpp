@@ -63,6 +63,11 @@ struct emspec_engine {
     size_t ring_bytes = 0;
     float* d_frame = nullptr;
     size_t frame_bytes = 0;
+    // per-frame streaming call without DMA: page-locked, device-visible host buffers the kernel reads the
+    // frame from and writes the finished column to (one launch + one sync per call)
+    float* h_frame = nullptr; size_t h_frame_bytes = 0;
+    float* h_coldb = nullptr;
+    uint8_t* h_colrgba = nullptr;
     float* d_coldb = nullptr;
     uint8_t* d_colrgba = nullptr;
     // display post-process (emspec_set_display)
@@ -246,6 +251,9 @@ void emspec_destroy(emspec_engine* e) {
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
     (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak); (void)hipFree(e->d_pstate);
     (void)hipFree(e->d_sbuf[0]); (void)hipFree(e->d_sbuf[1]); (void)hipFree(e->d_pushdb); (void)hipFree(e->d_pushrgba);
+    if (e->h_frame) (void)hipHostFree(e->h_frame);
+    if (e->h_coldb) (void)hipHostFree(e->h_coldb);
+    if (e->h_colrgba) (void)hipHostFree(e->h_colrgba);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     delete e;
@@ -669,18 +677,42 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     if ((rc = get_plan(e, n, &p))) return rc;
     const PlanDev pd = plan_dev(e, *p, hop, reassign);
     const int64_t j = e->st_fed;
-    HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
     FrameSinks sk;
     sk.hist = e->d_ring;
     sk.hist_slots = e->st_W;
     sk.total_cols = INT64_MAX;
     sk.ring = 1;
     sk.col_offset = j;   // the staged frame sits at offset 0 but is absolute frame j
-    HIPCHK(e, launch_frames(n, pd, e->d_frame, n, 1, 0, 1, sk, e->stream));
-    e->st_fed = j + 1;
     const int64_t c = j - e->st_D;   // column completed by this frame
+    const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
     if (out_column) *out_column = c >= 0 ? c : -1;
-    if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
+    if (!post && (out_db || out_rgba)) {
+        // One launch, no DMA: the frame's workgroup reads the samples from page-locked host memory, scatters,
+        // and emits the finished column straight into page-locked host memory (FrameSinks::fin_*).
+        if (e->h_frame_bytes < (size_t)n * 4) {
+            if (e->h_frame) { HIPCHK(e, hipHostFree(e->h_frame)); e->h_frame = nullptr; e->h_frame_bytes = 0; }
+            HIPCHK(e, hipHostMalloc((void**)&e->h_frame, (size_t)n * 4, hipHostMallocDefault));
+            e->h_frame_bytes = (size_t)n * 4;
+        }
+        if (!e->h_coldb) HIPCHK(e, hipHostMalloc((void**)&e->h_coldb, (size_t)4096 * 4, hipHostMallocDefault));
+        if (!e->h_colrgba) HIPCHK(e, hipHostMalloc((void**)&e->h_colrgba, (size_t)4096 * 4, hipHostMallocDefault));
+        std::memcpy(e->h_frame, frame, (size_t)n * 4);
+        sk.fin_db = out_db ? e->h_coldb : nullptr;
+        sk.fin_rgba = out_rgba ? reinterpret_cast<uint32_t*>(e->h_colrgba) : nullptr;
+        sk.fin_lut = reinterpret_cast<const uint32_t*>(e->d_lut);
+        sk.fin_col = c;
+        sk.fin_map = db_map(e, n);
+        HIPCHK(e, launch_frames(n, pd, e->h_frame, n, 1, 0, 1, sk, e->stream));
+        e->st_fed = j + 1;
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (out_db) std::memcpy(out_db, e->h_coldb, (size_t)R * 4);
+        if (out_rgba) std::memcpy(out_rgba, e->h_colrgba, (size_t)R * 4);
+    } else {
+        HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, launch_frames(n, pd, e->d_frame, n, 1, 0, 1, sk, e->stream));
+        e->st_fed = j + 1;
+        if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
+    }
     if (c >= 0) e->st_emitted = c + 1;
     return EMSPEC_OK;
 }

@@ -21,6 +21,13 @@ struct FrameSinks {
     int64_t total_cols = 0;    // valid absolute columns are [0,total_cols)
     int32_t ring = 0;          // !=0: slot = col % hist_slots (streaming ring), else slot = col
     int64_t col_offset = 0;    // added to the frame index to get its absolute column (streaming)
+    // streaming, one frame per launch: the frame's own workgroup also emits the column this frame completes
+    // (fin_col, or the empty column when < 0) from the ring and clears its slot - one launch instead of three
+    float* fin_db = nullptr;          // [rows] dB, or null
+    uint32_t* fin_rgba = nullptr;     // [rows] RGBA8, or null
+    const uint32_t* fin_lut = nullptr;
+    int64_t fin_col = -1;
+    DbMap fin_map{};
 };
 
 bool supported_fft(int n);

@@ -163,6 +163,22 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
             atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
         }
     }
+    if (sk.fin_db || sk.fin_rgba) {
+        // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
+        // frame's atomics are ordered by the fence + barrier, so column fin_col is complete: emit it and clear its
+        // ring slot here.  Slot hist_slots is the always-empty column (used while the ring primes).
+        __threadfence();
+        __syncthreads();
+        const int64_t slot = sk.fin_col >= 0 ? sk.fin_col % sk.hist_slots : sk.hist_slots;
+        float* cells = sk.hist + (size_t)slot * pl.rows;
+        for (int r = t; r < pl.rows; r += T) {
+            const float e = __hip_atomic_load(cells + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float d = cell_db(sk.fin_map, e);
+            if (sk.fin_db) sk.fin_db[r] = d;
+            if (sk.fin_rgba) sk.fin_rgba[r] = sk.fin_lut[cell_index(sk.fin_map, d)];
+            if (sk.fin_col >= 0) cells[r] = 0.0f;
+        }
+    }
 }
 
 bool supported_fft(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }

@@ -34,7 +34,7 @@ t0 = time.perf_counter()
 for j in range(20, 520):
     e.column(fr[j * hop:j * hop + n], hop, True)
 dt = (time.perf_counter() - t0) / 500
-print(f"emspec_column (streaming, one frame per call: H2D + 2 kernels + D2H + sync): {dt * 1e6:.1f} us per column "
+print(f"emspec_column (streaming, one frame per call: one launch reading and writing page-locked host memory + sync): {dt * 1e6:.1f} us per column "
       f"= {1 / dt:.0f} columns/s per engine (real time needs 187.5/s per stream)")
 for blk in (512, 2048, 16384, 131072):
     e.reset()
