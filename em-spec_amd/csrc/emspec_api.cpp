@@ -53,6 +53,7 @@ struct emspec_engine {
     int st_mode = 0;          // 0 idle, 1 per-frame (emspec_column), 2 per-sample-block (emspec_push_samples)
     int64_t st_have = 0;      // sample mode: samples buffered in d_sbuf[st_cur], first one is sample st_fed*hop
     int st_cur = 0;
+    std::vector<float> st_pending;   // sample mode: samples received since the last upload that complete no frame yet
     float* d_sbuf[2] = {nullptr, nullptr};
     size_t sbuf_bytes[2] = {0, 0};
     float* d_pushdb = nullptr; size_t pushdb_bytes = 0;
@@ -623,6 +624,7 @@ int emspec_reset(emspec_engine* e) {
     if (e->d_pstate) { (void)hipSetDevice(e->device); (void)hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream); }
     e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0; e->st_W = 0; e->st_mode = 0;
     e->st_fed = 0; e->st_emitted = 0; e->st_have = 0;
+    e->st_pending.clear();
     return EMSPEC_OK;
 }
 
@@ -731,7 +733,7 @@ int64_t emspec_push_columns(const emspec_engine* e, int64_t count, int32_t n, in
     const int D = latency(n, hop, reassign ? 1 : 0);
     const bool live = e->st_mode == 2;
     const int64_t fed = live ? e->st_fed : 0;
-    const int64_t seen = live ? e->st_fed * (int64_t)hop + e->st_have : 0;
+    const int64_t seen = live ? e->st_fed * (int64_t)hop + e->st_have + (int64_t)e->st_pending.size() : 0;
     const int64_t after = frames_after(seen + count, n, hop);
     const int64_t before_cols = fed > D ? fed - D : 0, after_cols = after > D ? after - D : 0;
     return after_cols - before_cols;
@@ -778,11 +780,21 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
         HIPCHK(e, hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream));
     }
     const int D = e->st_D, W = e->st_W;
-    int64_t produced = 0, first = -1, used = 0;
-    while (used < count) {
-        const int64_t take = std::min<int64_t>(count - used, (int64_t)cap - e->st_have);
+    int64_t produced = 0, first = -1;
+    // A block that completes no frame (an audio worklet hands over 128 samples at a time) only joins the host-side
+    // pending samples: no copy, no launch, no synchronisation until a frame is due.
+    if (frames_after(e->st_have + (int64_t)e->st_pending.size() + count, n, hop) == 0) {
+        e->st_pending.insert(e->st_pending.end(), samples, samples + count);
+        if (out_count) *out_count = 0;
+        if (out_first_column) *out_first_column = -1;
+        return EMSPEC_OK;
+    }
+    auto feed = [&](const float* src, int64_t cnt) -> int {
+    int64_t used = 0;
+    while (used < cnt) {
+        const int64_t take = std::min<int64_t>(cnt - used, (int64_t)cap - e->st_have);
         float* buf = e->d_sbuf[e->st_cur];
-        HIPCHK(e, hipMemcpyAsync(buf + e->st_have, samples + used, (size_t)take * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(buf + e->st_have, src + used, (size_t)take * 4, hipMemcpyHostToDevice, e->stream));
         used += take;
         e->st_have += take;
         const int64_t M = frames_after(e->st_have, n, hop);   // <= kPushFrames by the size of the buffer
@@ -829,7 +841,12 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
         e->st_have = keep;
         e->st_fed = j0 + M;
     }
+    return EMSPEC_OK;
+    };
+    if (!e->st_pending.empty() && (rc = feed(e->st_pending.data(), (int64_t)e->st_pending.size()))) return rc;
+    if ((rc = feed(samples, count))) return rc;
     HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->st_pending.clear();   // only now: its upload above was asynchronous
     if (out_count) *out_count = produced;
     if (out_first_column) *out_first_column = first;
     return EMSPEC_OK;

@@ -36,7 +36,7 @@ for j in range(20, 520):
 dt = (time.perf_counter() - t0) / 500
 print(f"emspec_column (streaming, one frame per call: one launch reading and writing page-locked host memory + sync): {dt * 1e6:.1f} us per column "
       f"= {1 / dt:.0f} columns/s per engine (real time needs 187.5/s per stream)")
-for blk in (512, 2048, 16384, 131072):
+for blk in (128, 512, 2048, 16384, 131072):
     e.reset()
     e.push_samples(fr[:n + 16 * hop], n, hop, True)
     pos, cols = n + 16 * hop, 0
@@ -46,6 +46,6 @@ for blk in (512, 2048, 16384, 131072):
         cols += len(db)
         pos += blk
     dt = time.perf_counter() - t0
-    print(f"emspec_push_samples (streaming, blocks of {blk} samples = {blk // hop} columns per call): "
+    print(f"emspec_push_samples (streaming, blocks of {blk} samples = {blk / hop:g} columns per call): "
           f"{dt / max(cols, 1) * 1e6:.1f} us per column = {cols / dt:.3e} columns/s per engine")
 e.reset()
