@@ -5,10 +5,12 @@
 // /root/reference/README.md:73); the contract is SURVEY.md §8(b).
 // There is deliberately NO CPU path here: without a gfx950 device
 // emspec_create fails.
-#include "../../include/emspec.h"
+#include "emspec_engine.h"
+#ifdef EMSPEC_DIAG
+#pragma GCC visibility push(default)
 #include "../../include/emspec_debug.h"
-#include "emspec_launch.h"
-
+#pragma GCC visibility pop
+#endif
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -20,79 +22,24 @@
 using namespace emspec;
 
 namespace {
-
 thread_local std::string g_create_error = "";
-
-struct Plan {
-    int n = 0;
-    float2* d_tw = nullptr;
-    float* d_ebin = nullptr;
-    std::vector<float> h_tw, h_ebin;
-};
-
 }  // namespace
 
-struct emspec_engine {
-    emspec_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second lane of the host-buffer batch pipeline
-    std::string arch;
-    mutable std::string err;
-    std::map<int, Plan> plans;
-    std::vector<float> custom_edges_hz;   // rows+1 entries when emspec_set_row_edges_hz was called
-    uint8_t* d_lut = nullptr;
-    // batch workspace (generic path per-bin records; host-API staging)
-    float* d_hist = nullptr;
-    size_t hist_bytes = 0;
-    char* d_stage = nullptr;
-    size_t stage_bytes = 0;
-    // streaming state
-    int st_n = 0, st_hop = 0, st_reassign = -1, st_D = 0;
-    int st_W = 0;             // ring slots (2D+1 per-frame mode, 2D+kPushFrames sample mode); slot st_W is the empty column
-    int st_mode = 0;          // 0 idle, 1 per-frame (emspec_column), 2 per-sample-block (emspec_push_samples)
-    int64_t st_have = 0;      // sample mode: samples buffered in d_sbuf[st_cur], first one is sample st_fed*hop
-    int st_cur = 0;
-    std::vector<float> st_pending;   // sample mode: samples received since the last upload that complete no frame yet
-    float* d_sbuf[2] = {nullptr, nullptr};
-    size_t sbuf_bytes[2] = {0, 0};
-    float* d_pushdb = nullptr; size_t pushdb_bytes = 0;
-    uint8_t* d_pushrgba = nullptr; size_t pushrgba_bytes = 0;
-    int64_t st_fed = 0;       // frames fed so far
-    int64_t st_emitted = 0;   // columns emitted so far (flush included)
-    float* d_ring = nullptr;  // [W+1][rows]; slot W stays zero (the empty column)
-    size_t ring_bytes = 0;
-    float* d_frame = nullptr;
-    size_t frame_bytes = 0;
-    // per-frame streaming call without DMA: page-locked, device-visible host buffers the kernel reads the
-    // frame from and writes the finished column to (one launch + one sync per call)
-    float* h_frame = nullptr; size_t h_frame_bytes = 0;
-    float* h_coldb = nullptr;
-    uint8_t* h_colrgba = nullptr;
-    float* d_coldb = nullptr;
-    uint8_t* d_colrgba = nullptr;
-    // display post-process (emspec_set_display)
-    float smoothing = 0.0f, agc = 0.0f;
-    float* d_raw = nullptr; size_t raw_bytes = 0;      // raw dB columns of a batch
-    float* d_post = nullptr; size_t post_bytes = 0;    // post-processed dB when the caller wants none
-    float* d_peak = nullptr; size_t peak_bytes = 0;    // column peaks + gains
-    float* d_pstate = nullptr;                         // streaming: [0]=AGC level, [1]=initialised, [2..]=previous column
-};
-
-namespace {
-
+namespace emspec {
 int fail(const emspec_engine* e, int code, const std::string& msg) {
     if (e) e->err = msg; else g_create_error = msg;
     return code;
 }
+int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
+    if (*have >= want) return EMSPEC_OK;
+    if (*ptr) { HIPCHK(e, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
+    HIPCHK(e, hipMalloc(ptr, want));
+    *have = want;
+    return EMSPEC_OK;
+}
+}  // namespace emspec
 
-#define HIPCHK(e, call)                                                                          \
-    do {                                                                                         \
-        hipError_t _r = (call);                                                                  \
-        if (_r != hipSuccess)                                                                    \
-            return fail((e), _r == hipErrorOutOfMemory ? EMSPEC_ERR_OUT_OF_MEMORY : EMSPEC_ERR_HIP, \
-                        std::string(#call) + ": " + hipGetErrorString(_r));                      \
-    } while (0)
+namespace {
 
 void default_lut(uint8_t* lut) {
     // 5-stop gradient measured from the reference's settings screenshot
@@ -174,14 +121,6 @@ DbMap db_map(const emspec_engine* e, int n) {
     return m;
 }
 
-int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
-    if (*have >= want) return EMSPEC_OK;
-    if (*ptr) { HIPCHK(e, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
-    HIPCHK(e, hipMalloc(ptr, want));
-    *have = want;
-    return EMSPEC_OK;
-}
-
 }  // namespace
 
 static void drop_plans(emspec_engine* e);
@@ -247,6 +186,7 @@ void emspec_destroy(emspec_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    comm_destroy(e);
     drop_plans(e);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
@@ -428,6 +368,7 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     return run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, db, rgba, index, st);
 }
 
+#ifdef EMSPEC_DIAG   // diagnostic entry points (include/emspec_debug.h): libemspec_diag.so only
 // Diagnostic: non-zero if a bounded spin of the decoupled-team fused kernel ever timed out on this device.
 int emspec_debug_fused_error(emspec_engine* e) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
@@ -499,6 +440,7 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
     HIPCHK(e, r);
     return EMSPEC_OK;
 }
+#endif  // EMSPEC_DIAG
 
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
                  const emspec_out* out) {
@@ -527,7 +469,9 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     const bool pinned = is_pinned(pcm) && is_pinned(out->db) && is_pinned(out->rgba) && is_pinned(out->index);
     // pageable copies are staged synchronously by the runtime: chunking only adds overhead there;
     // the generic path shares one record workspace, so it stays on one stream too
-    const bool two = pinned && fused_supported(n, hop, e->cfg.rows, reassign) && S > 1;
+    // ... and so does the display post-process (raw dB / peak / post workspaces are per engine, not per lane)
+    const bool display = e->smoothing > 0.0f || e->agc > 0.0f;
+    const bool two = pinned && fused_supported(n, hop, e->cfg.rows, reassign) && S > 1 && !display;
     if (two && !e->stream2 && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
         unpin();
         return fail(e, EMSPEC_ERR_HIP, "hipStreamCreate failed");
@@ -590,7 +534,9 @@ int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
     if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
     int rc = check_shape(e, n, hop);
     if (rc) return rc;
-    if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
+    if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
+    if (frame0 < 0 || nframes < 0 || frame0 + nframes > emspec_num_columns(L, n, hop))
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "frame range outside the stream");
     HIPCHK(e, hipSetDevice(e->device));
     const size_t nb = (size_t)S * nframes * (n / 2 + 1);
     const size_t b_pcm = (size_t)S * L * sizeof(float);
@@ -663,15 +609,15 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     HIPCHK(e, hipSetDevice(e->device));
     const int R = e->cfg.rows;
     if (e->st_reassign < 0) {
-        // first frame of a stream: set up the ring
-        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = latency(n, hop, reassign);
-        e->st_mode = 1;
-        const int W = e->st_W = 2 * e->st_D + 1;
+        // first frame of a stream: set up the ring; the stream state is committed only after every allocation succeeded
+        const int D = latency(n, hop, reassign), W = 2 * D + 1;
         if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
         if ((rc = grow(e, (void**)&e->d_frame, &e->frame_bytes, (size_t)n * 4))) return rc;
         if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
         if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
         HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
+        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W;
+        e->st_mode = 1;
     } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 1) {
         return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
     }
@@ -843,9 +789,19 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
     }
     return EMSPEC_OK;
     };
-    if (!e->st_pending.empty() && (rc = feed(e->st_pending.data(), (int64_t)e->st_pending.size()))) return rc;
-    if ((rc = feed(samples, count))) return rc;
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    // A failure inside feed() leaves copies from `samples` / into the outputs in flight and the stream position half
+    // advanced: drain the stream (the buffers are only borrowed for this call) and drop the stream state, so the
+    // caller restarts from emspec_reset() semantics instead of silently re-feeding the pending samples.
+    auto abandon = [&](int code) {
+        const std::string msg = e->err;
+        (void)hipStreamSynchronize(e->stream);
+        (void)emspec_reset(e);
+        e->err = msg + " (stream state was reset)";
+        return code;
+    };
+    if (!e->st_pending.empty() && (rc = feed(e->st_pending.data(), (int64_t)e->st_pending.size()))) return abandon(rc);
+    if ((rc = feed(samples, count))) return abandon(rc);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return abandon(fail(e, EMSPEC_ERR_HIP, "hipStreamSynchronize failed"));
     e->st_pending.clear();   // only now: its upload above was asynchronous
     if (out_count) *out_count = produced;
     if (out_first_column) *out_first_column = first;

@@ -1,0 +1,86 @@
+// emspec_engine.h — internal: the engine object behind the C ABI (include/emspec.h), shared by
+// emspec_api.cpp (engine, batch, streaming) and emspec_comm.cpp (RCCL gather of finished columns).
+#pragma once
+// the library is built with -fvisibility=hidden: only the C ABI of include/emspec.h is exported
+#pragma GCC visibility push(default)
+#include "../../include/emspec.h"
+#pragma GCC visibility pop
+#include "emspec_launch.h"
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace emspec {
+struct Plan {
+    int n = 0;
+    float2* d_tw = nullptr;
+    float* d_ebin = nullptr;
+    std::vector<float> h_tw, h_ebin;
+};
+}  // namespace emspec
+
+struct emspec_engine {
+    emspec_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second lane of the host-buffer batch pipeline
+    std::string arch;
+    mutable std::string err;
+    std::map<int, emspec::Plan> plans;
+    std::vector<float> custom_edges_hz;   // rows+1 entries when emspec_set_row_edges_hz was called
+    uint8_t* d_lut = nullptr;
+    // batch workspace (generic path per-bin records; host-API staging)
+    float* d_hist = nullptr;
+    size_t hist_bytes = 0;
+    char* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // streaming state
+    int st_n = 0, st_hop = 0, st_reassign = -1, st_D = 0;
+    int st_W = 0;             // ring slots (2D+1 per-frame mode, 2D+kPushFrames sample mode); slot st_W is the empty column
+    int st_mode = 0;          // 0 idle, 1 per-frame (emspec_column), 2 per-sample-block (emspec_push_samples)
+    int64_t st_have = 0;      // sample mode: samples buffered in d_sbuf[st_cur], first one is sample st_fed*hop
+    int st_cur = 0;
+    std::vector<float> st_pending;   // sample mode: samples received since the last upload that complete no frame yet
+    float* d_sbuf[2] = {nullptr, nullptr};
+    size_t sbuf_bytes[2] = {0, 0};
+    float* d_pushdb = nullptr; size_t pushdb_bytes = 0;
+    uint8_t* d_pushrgba = nullptr; size_t pushrgba_bytes = 0;
+    int64_t st_fed = 0;       // frames fed so far
+    int64_t st_emitted = 0;   // columns emitted so far (flush included)
+    float* d_ring = nullptr;  // [W+1][rows]; slot W stays zero (the empty column)
+    size_t ring_bytes = 0;
+    float* d_frame = nullptr;
+    size_t frame_bytes = 0;
+    // per-frame streaming call without DMA: page-locked, device-visible host buffers the kernel reads the
+    // frame from and writes the finished column to (one launch + one sync per call)
+    float* h_frame = nullptr; size_t h_frame_bytes = 0;
+    float* h_coldb = nullptr;
+    uint8_t* h_colrgba = nullptr;
+    float* d_coldb = nullptr;
+    uint8_t* d_colrgba = nullptr;
+    // display post-process (emspec_set_display)
+    float smoothing = 0.0f, agc = 0.0f;
+    float* d_raw = nullptr; size_t raw_bytes = 0;      // raw dB columns of a batch
+    float* d_post = nullptr; size_t post_bytes = 0;    // post-processed dB when the caller wants none
+    float* d_peak = nullptr; size_t peak_bytes = 0;    // column peaks + gains
+    float* d_pstate = nullptr;                         // streaming: [0]=AGC level, [1]=initialised, [2..]=previous column
+    // multi-GPU gather of finished columns (emspec_comm.cpp); opaque here so this header needs no rccl.h
+    struct emspec_comm_state* comm = nullptr;
+};
+
+namespace emspec {
+// records the message on the engine (or, for e == nullptr, as the thread's emspec_create error) and returns code
+int fail(const emspec_engine* e, int code, const std::string& msg);
+// (re)allocates *ptr to at least `want` bytes of device memory
+int grow(emspec_engine* e, void** ptr, size_t* have, size_t want);
+void comm_destroy(emspec_engine* e);   // emspec_comm.cpp: called by emspec_destroy
+}  // namespace emspec
+
+#define HIPCHK(e, call)                                                                          \
+    do {                                                                                         \
+        hipError_t _r = (call);                                                                  \
+        if (_r != hipSuccess)                                                                    \
+            return emspec::fail((e), _r == hipErrorOutOfMemory ? EMSPEC_ERR_OUT_OF_MEMORY : EMSPEC_ERR_HIP, \
+                                std::string(#call) + ": " + hipGetErrorString(_r));              \
+    } while (0)

@@ -58,11 +58,13 @@ hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uin
 hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut,
                               uint8_t* rgba, float* state, float* yprev, hipStream_t st);
 bool fused_supported(int n, int hop, int rows, int reassign);
+int device_cus();           // compute units of the current device
+#ifdef EMSPEC_DIAG          // diagnostic build only (libemspec_diag.so, include/emspec_debug.h)
 int fused_waves_per_group();
 int fused_read_errflag();   // non-zero if a bounded spin of the decoupled-team kernel ever timed out
 hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh, int64_t count, int32_t* out_hint,
                                    int32_t* out_exact, hipStream_t st);
-
 hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st);
+#endif
 
 }  // namespace emspec

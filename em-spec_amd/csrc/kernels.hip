@@ -13,9 +13,40 @@
 //   fused kernels          see fused.hip.inc (LDS column ring, batch path).
 #include "emspec_launch.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace emspec {
+
+// Kernels that need more than 64 KB of dynamic LDS must say so once per (device, kernel).  Engines on different
+// threads may launch concurrently, so the "already done" set is guarded; the HIP call itself is idempotent.
+static hipError_t allow_max_lds(const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, fn})) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({dev, fn});
+    return e;
+}
+// compute units of the current device (grid sizing: workgroups per launch are counted in rounds of CUs)
+int device_cus() {
+    static std::mutex mu;
+    static int cus[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    int& c = cus[dev & 63];
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    }
+    return c;
+}
 
 // ---------------------------------------------------------------------------
 // FFT passes over the in-place LDS buffer.  16 points per thread, T = N/16.
@@ -189,15 +220,9 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     constexpr int N = 1 << LOG2N;
     const size_t lds = (size_t)(PaddedSize<N>::value + mid_tw_entries(LOG2N)) * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done[64] = {};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_done[dev_ & 63];   // the attribute is per device
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&frames_kernel<LOG2N>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024) {
+        const hipError_t e = allow_max_lds(reinterpret_cast<const void*>(&frames_kernel<LOG2N>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     // grid.x is limited to 2^31-1, grid.y to 65535
     if (nframes <= 0 || S <= 0) return hipSuccess;
@@ -298,15 +323,9 @@ template <int CH>
 static hipError_t launch_tile_scatter_t(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                                         int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
                                         int tile, size_t lds) {
-    static bool attr_done[64] = {};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_done[dev_ & 63];   // the attribute is per device
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_scatter_kernel<CH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        const hipError_t e = allow_max_lds(reinterpret_cast<const void*>(&tile_scatter_kernel<CH>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int64_t ntiles = (C + tile - 1) / tile;
     hipLaunchKernelGGL(tile_scatter_kernel<CH>, dim3((unsigned)ntiles, (unsigned)S), dim3(1024), lds, st, records,
@@ -399,17 +418,11 @@ template <int CH>
 static hipError_t launch_walk_scatter_t(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                                         int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st, int F,
                                         size_t lds) {
-    static bool attr_done[64] = {};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    bool& attr_set = attr_done[dev_ & 63];   // the attribute is per device
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&walk_scatter_kernel<CH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {
+        const hipError_t e = allow_max_lds(reinterpret_cast<const void*>(&walk_scatter_kernel<CH>));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
-    int64_t seg = (S * C + 1023) / 1024;                 // >= 4 workgroups per CU when there is enough work
+    int64_t seg = (S * C + 4 * device_cus() - 1) / (4 * device_cus());   // >= 4 workgroups per CU when there is enough work
     seg = seg < 128 ? 128 : (seg > 1024 ? 1024 : seg);
     seg = (seg + F - 1) / F * F;
     const int64_t nseg = (C + seg - 1) / seg;
@@ -429,8 +442,12 @@ hipError_t launch_tile_scatter(const uint2* records, int n, const PlanDev& pl, c
         int F = (1024 + nch - 1) / nch;
         F = F < 1 ? 1 : (F > 8 ? 8 : F);
         const size_t wl = (size_t)(2 * pl.D + F) * pl.rows * 4 + 1024;
+#ifdef EMSPEC_DIAG
         static int use_walk = -1;
         if (use_walk < 0) { const char* ev = getenv("EMSPEC_NO_WALK"); use_walk = (ev && ev[0] == '1') ? 0 : 1; }   // A/B aid
+#else
+        constexpr bool use_walk = true;
+#endif
         // measured: the walk wins when the tiles would re-read every record >= 2x (D >= 16: N=16384/512
         // 1.04e7 vs 0.94e7 col/s); for small D the tiles' independent workgroups win (N=1024: 1.8e8 vs 1.6e8)
         if (use_walk && pl.D >= 16 && wl <= 156 * 1024) {
@@ -482,6 +499,7 @@ hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, co
     return hipGetLastError();
 }
 
+#ifdef EMSPEC_DIAG
 // diagnostic: both row-lookup implementations on arbitrary inputs (tests only)
 __global__ void row_lookup_probe_kernel(const float* __restrict__ ebin, int rows, const float* __restrict__ kh,
                                         int64_t count, int32_t* __restrict__ out_hint, int32_t* __restrict__ out_exact) {
@@ -522,6 +540,7 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
     hipLaunchKernelGGL(occupy_kernel, dim3(groups), dim3(256), 0, st, (long long)usec * 100, sink);
     return hipGetLastError();
 }
+#endif  // EMSPEC_DIAG
 
 }  // namespace emspec
 

@@ -13,6 +13,9 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_PKG)                 # em-spec_amd/
 LIB_PATH = os.path.join(ROOT, "libemspec.so")
+# the same sources built with -DEMSPEC_DIAG: adds include/emspec_debug.h, the stamped / A-B kernel builds and the
+# EMSPEC_* environment switches.  Tools and the tests that probe internals load this one; the product never does.
+DIAG_LIB_PATH = os.path.join(ROOT, "libemspec_diag.so")
 
 ABI_VERSION = 1
 OK = 0
@@ -44,17 +47,18 @@ class EmspecError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libemspec.so (built in-tree by __graft_entry__.build()). Raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = C.CDLL(LIB_PATH)
+def load(diag=False):
+    """Load libemspec.so (or, diag=True, libemspec_diag.so), built in-tree by __graft_entry__.build().
+    Raises if absent: there is no fallback."""
+    if diag in _libs:
+        return _libs[diag]
+    path = DIAG_LIB_PATH if diag else LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(path)
     lib.emspec_last_error.restype = C.c_char_p
     lib.emspec_last_error.argtypes = [C.c_void_p]
     lib.emspec_device_arch.restype = C.c_char_p
@@ -90,7 +94,7 @@ def load():
     lib.emspec_host_free.restype = None
     lib.emspec_set_display.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-    _lib = lib
+    _libs[diag] = lib
     return lib
 
 
@@ -167,8 +171,8 @@ def _np_ptr(a):
 class Engine:
     """One engine = one HIP device + stream (not thread-safe), see emspec.h."""
 
-    def __init__(self, cfg=None, **kw):
-        self._lib = load()
+    def __init__(self, cfg=None, diag=False, **kw):
+        self._lib = load(diag)
         self.cfg = cfg if cfg is not None else default_config(**kw)
         h = C.c_void_p()
         rc = self._lib.emspec_create(C.byref(self.cfg), C.byref(h))

@@ -20,3 +20,12 @@ def engine():
     e = emspec.Engine()
     yield e
     e.close()
+
+
+@pytest.fixture(scope="session")
+def diag_engine():
+    """Engine of libemspec_diag.so (the product sources + include/emspec_debug.h), for tests that probe internals."""
+    import emspec
+    e = emspec.Engine(diag=True)
+    yield e
+    e.close()

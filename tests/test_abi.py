@@ -15,24 +15,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HAS_GPU = torch.cuda.is_available()
 
 
-def declared_functions():
-    names = set()
-    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if h.endswith(".h"):
-            src = open(os.path.join(ROOT, "include", h)).read()
-            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-            names |= set(re.findall(r"\b(emspec_[a-z_0-9]+)\s*\(", src))
-    return sorted(names)
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(emspec_[a-z_0-9]+)\s*\(", src)))
+
+
+def exported_functions(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("emspec_")})
 
 
 def test_header_symbols_exported():
+    """The product library exports exactly what include/emspec.h declares: no diagnostic entry points."""
     lib = emspec.load()
-    names = declared_functions()
+    names = declared_functions("emspec.h")
     assert len(names) >= 15
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/emspec.h but not exported by libemspec.so"
     assert set(emspec.SYMBOLS) <= set(names)
-    assert "emspec_debug_row_lookup" in names and "emspec_debug_phase_cycles" in names
+    assert exported_functions(emspec.LIB_PATH) == names
+
+
+def test_diag_library_adds_only_the_debug_header():
+    dbg = declared_functions("emspec_debug.h")
+    assert "emspec_debug_row_lookup" in dbg and "emspec_debug_phase_cycles" in dbg
+    assert exported_functions(emspec.DIAG_LIB_PATH) == sorted(set(declared_functions("emspec.h")) | set(dbg))
+    out = subprocess.run(["strings", "-n", "6", emspec.LIB_PATH], capture_output=True, text=True).stdout
+    for needle in ("EMSPEC_FUSED_VARIANT", "EMSPEC_NO_FUSED", "EMSPEC_SEGLEN", "EMSPEC_NO_WALK", "fused4096_r8t", "occupy_kernel"):
+        assert needle not in out, f"{needle} is diagnostic and must not be in libemspec.so"
 
 
 def test_library_has_gfx950_code_object():

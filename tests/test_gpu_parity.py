@@ -122,6 +122,59 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
 
 
+@pytest.mark.parametrize("hop,frames,S,reassign,rows", [(512, 150, 2, True, 1024), (512, 40, 1, True, 1024), (512, 9, 2, True, 1024),
+                                                         (512, 1, 1, True, 1024), (1024, 90, 2, True, 1024), (2048, 70, 1, True, 1024),
+                                                         (16384, 5, 2, True, 1024), (700, 60, 1, True, 1024), (512, 130, 2, False, 1024),
+                                                         (100, 200, 1, False, 1024), (512, 80, 2, True, 256), (384, 40, 1, True, 512)])
+def test_fused_n16384_matches_oracle(hop, frames, S, reassign, rows):
+    """BASELINE configs[4] shape (FFT 16384): the fused walking kernel whose column ring is parked in registers while
+    the FFT owns the LDS.  Several segments per stream (the launcher cuts >= 128-column segments), fewer frames than
+    the reassignment reach (2D = 32), one frame, other hops / row counts, reassignment off (D = 0: one ring slot)."""
+    import emspec
+    n = 16384
+    pcm = _pcm(n, hop, frames, S=S)
+    eng = emspec.Engine(rows=rows)
+    try:
+        assert eng.fused(n, hop, reassign)
+        out = eng.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
+    finally:
+        eng.close()
+    odb, orgba, oidx = O.batch_f32(O.make_cfg(n, hop, reassign, rows=rows), pcm)
+    assert out["db"].shape == odb.shape == (S, frames, rows)
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
+
+
+@pytest.mark.parametrize("hop,seglen,frames", [(512, 130, 600), (512, 33, 200), (1024, 65, 300)])
+def test_fused_n16384_short_segments(hop, seglen, frames, monkeypatch):
+    """Same kernel with many short segments per stream (each recomputes a 2D-frame halo), odd segment lengths."""
+    import emspec
+    n = 16384
+    monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
+    pcm = _pcm(n, hop, frames, S=2)
+    eng = emspec.Engine(diag=True)      # EMSPEC_SEGLEN is a switch of the diagnostic build (same kernel sources)
+    try:
+        out = eng.batch(pcm, n, hop, True, want=("db", "index"))
+    finally:
+        eng.close()
+    odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+
+
+def test_generic_records_path_still_serves_n16384_small_hop(engine):
+    """N = 16384 at hop 256 needs 65 ring slots: not fused, stays on per-bin records + walk/tile scatter."""
+    n, hop, frames = 16384, 256, 80
+    assert not engine.fused(n, hop, True)
+    pcm = _pcm(n, hop, frames, S=1)
+    out = engine.batch(pcm, n, hop, True, want=("db",))
+    odb, _, _ = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db",))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+
+
 @pytest.mark.parametrize("n,hop,seglen", [(4096, 512, 66), (4096, 512, 250), (4096, 1024, 64), (4096, 1024, 130),
                                           (8192, 512, 65), (8192, 512, 131), (8192, 1024, 64), (8192, 1024, 99),
                                           (2048, 128, 67), (2048, 256, 130), (2048, 777, 64), (1024, 256, 65), (1024, 128, 101),
@@ -133,7 +186,7 @@ def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
     monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
     frames, S = (400 if n == 8192 else 700), 2
     pcm = _pcm(n, hop, frames, S=S)
-    eng = emspec.Engine()
+    eng = emspec.Engine(diag=True)      # EMSPEC_SEGLEN is a switch of the diagnostic build (same kernel sources)
     try:
         assert eng.fused(n, hop, True)
         out = eng.batch(pcm, n, hop, True, want=("db", "index"))
@@ -145,13 +198,14 @@ def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
     assert d.max() <= 1 and np.mean(d != 0) < 1e-3
 
 
-def test_hinted_row_lookup_equals_binary_search(engine):
+def test_hinted_row_lookup_equals_binary_search(diag_engine):
     """The fused kernels find the log-frequency row with a log2 hint + exact table compares.
     Sweep every table edge with its float32 neighbours (+-1, +-2 ulp), row midpoints, values
     just outside the table, zeros, negatives, inf and NaN: must equal the binary search."""
     import ctypes as C
     import emspec
-    lib = emspec.load()
+    engine = diag_engine
+    lib = emspec.load(diag=True)
     f = lib.emspec_debug_row_lookup
     f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     for n in (1024, 4096, 16384):
@@ -370,11 +424,12 @@ def test_custom_row_edges(n, hop):
     assert np.max(np.abs(back["db"] - odb_log)) < 8.7e-4
 
 
-def test_no_spin_timeouts(engine):
-    """The decoupled-team fused kernel bounds every wait; a timeout (protocol bug) raises a device flag."""
+def test_no_spin_timeouts(diag_engine):
+    """The decoupled-team fused kernel (diagnostic build only) bounds every wait; a timeout raises a device flag."""
     import ctypes as C
     import emspec
-    lib = emspec.load()
+    engine = diag_engine
+    lib = emspec.load(diag=True)
     lib.emspec_debug_fused_error.argtypes = [C.c_void_p]
     assert lib.emspec_debug_fused_error(engine._h) == 0
 
