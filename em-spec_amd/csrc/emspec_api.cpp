@@ -75,6 +75,13 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
         p.h_tw[2 * q] = (float)std::cos(a);
         p.h_tw[2 * q + 1] = (float)(-std::sin(a));
     }
+    // Second quarter by symmetry: tw[q + N/4] = -j tw[q] = (tw[q].im, -tw[q].re).  With a correctly rounded libm this is
+    // what cos/sin give anyway (checked for every N here); writing it down makes it a property of the table that the
+    // kernels may rely on (fused_n16384.hip.inc loads 8 pass-1 twiddles instead of 15).  oracle/emspec_oracle.c does the same.
+    for (int q = 0; q < n / 4; ++q) {
+        p.h_tw[2 * (q + n / 4)] = p.h_tw[2 * q + 1];
+        p.h_tw[2 * (q + n / 4) + 1] = -p.h_tw[2 * q];
+    }
     p.h_tw[2 * (n / 4)] = 0.0f;       // quarter turn is exact: (0,-1)
     p.h_tw[2 * (n / 4) + 1] = -1.0f;
     const int R = e->cfg.rows;

@@ -85,7 +85,10 @@ __device__ __forceinline__ void stage_mid_twiddles(float2* stw, const float2* __
     }
 }
 
-template <int LOG2N, int S0>
+// INPLACE: the last pass writes its results back where it read them (position p then holds Z[bitrev(p)]) and
+// issues no barrier: the caller synchronises before other waves read the spectrum.
+// PRIO: lower the wave's priority by one after each pass (progress-based priority, see fused_n16384.hip.inc).
+template <int LOG2N, int S0, bool INPLACE = false, bool PRIO = false>
 __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, const float2* __restrict__ tw) {
     constexpr int REM = LOG2N - S0;
     if constexpr (REM > 4) {
@@ -100,7 +103,8 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm[padi(base + (i << B0))] = v[i];
         wave_lds_sync();
-        fft_rest<LOG2N, S0 + 4>(sm, stw + (15 << B0), t, tw);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(3 - S0 / 4);   // S0 = 4 -> 2, S0 = 8 -> 1
+        fft_rest<LOG2N, S0 + 4, INPLACE, PRIO>(sm, stw + (15 << B0), t, tw);
     } else {
         // last pass: stages S0..LOG2N-1 (R = REM <= 4), G consecutive groups per thread
         // (positions 16t .. 16t+15: wave-local); output rewritten in natural frequency
@@ -113,6 +117,13 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 #pragma unroll
             for (int i = 0; i < (1 << R); ++i) v[gi][i] = sm[padi((g << R) + i)];
             fft_stages<LOG2N, S0, R>(v[gi], 0, tw);
+        }
+        if constexpr (INPLACE) {
+#pragma unroll
+            for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+                for (int i = 0; i < (1 << R); ++i) sm[padi(((G * t + gi) << R) + i)] = v[gi][i];
+            return;
         }
         __syncthreads();
 #pragma unroll
@@ -546,3 +557,4 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
 
 #include "fused.hip.inc"
 #include "post.hip.inc"
+#include "pack.hip.inc"

@@ -19,7 +19,9 @@ DIAG_LIB_PATH = os.path.join(ROOT, "libemspec_diag.so")
 
 ABI_VERSION = 1
 OK = 0
-ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE = -1, -2, -3, -4, -5
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_COMM = -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
+GATHER_LOOPBACK = 1
 
 SYMBOLS = [
     "emspec_default_config", "emspec_create", "emspec_destroy", "emspec_last_error", "emspec_set_colormap",
@@ -28,6 +30,8 @@ SYMBOLS = [
     "emspec_get_tables", "emspec_device_arch", "emspec_uses_fused", "emspec_set_row_edges_hz",
     "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free", "emspec_set_display",
     "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
+    "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
+    "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack",
 ]
 
 
@@ -94,6 +98,17 @@ def load(diag=False):
     lib.emspec_host_free.restype = None
     lib.emspec_set_display.argtypes = [C.c_void_p, C.c_float, C.c_float]
     lib.emspec_get_tables.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.emspec_comm_unique_id.argtypes = [C.c_void_p]
+    lib.emspec_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.emspec_comm_destroy.argtypes = [C.c_void_p]
+    lib.emspec_comm_rank.argtypes = [C.c_void_p]
+    lib.emspec_comm_world.argtypes = [C.c_void_p]
+    lib.emspec_gather_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                          C.POINTER(C.c_int64)]
+    lib.emspec_wire_bound.restype = C.c_int64
+    lib.emspec_wire_bound.argtypes = [C.c_int64, C.c_int32]
+    lib.emspec_wire_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+    lib.emspec_wire_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     _libs[diag] = lib
     return lib
 
@@ -158,6 +173,19 @@ def make_colormap(brightness=0.5):
     if lib.emspec_make_colormap(brightness, _np_ptr(out)) != OK:
         raise EmspecError(ERR_INVALID_ARG, "invalid brightness")
     return out
+
+
+def comm_unique_id():
+    """128-byte communicator id: rank 0 creates it and hands it to the other ranks (any host channel)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = load().emspec_comm_unique_id(buf)
+    if rc != OK:
+        raise EmspecError(rc, load().emspec_last_error(None).decode())
+    return bytes(buf)
+
+
+def wire_bound(columns, rows):
+    return int(load().emspec_wire_bound(columns, rows))
 
 
 def latency_columns(n, hop, reassign=True):
@@ -265,6 +293,58 @@ class Engine:
             assert t is None or (t.is_cuda and t.is_contiguous())
         self._chk(self._lib.emspec_batch_device(self._h, ptr(pcm_t), S, L, n, hop, int(bool(reassign)), ptr(db),
                                                 ptr(rgba), ptr(index), C.c_void_p(st.cuda_stream)))
+
+    # -- multi-GPU: RCCL communicator + gather of finished palette-index columns ----
+    def comm_init(self, comm_id, rank, world):
+        """Collective over all `world` ranks (one engine / process per GPU); comm_id from comm_unique_id() of rank 0."""
+        assert len(comm_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._chk(self._lib.emspec_comm_init(self._h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._chk(self._lib.emspec_comm_destroy(self._h))
+
+    @property
+    def comm_rank(self):
+        return int(self._lib.emspec_comm_rank(self._h))
+
+    @property
+    def comm_world(self):
+        return int(self._lib.emspec_comm_world(self._h))
+
+    def gather_columns(self, index_t, root=0, out=None, stream=None, loopback=False):
+        """index_t: contiguous uint8 CUDA tensor [..., rows] of this rank's finished columns; out (root only):
+        uint8 CUDA tensor [world, ...same shape...].  Returns the bytes this rank put on the wire."""
+        import torch
+        assert index_t.is_cuda and index_t.dtype == torch.uint8 and index_t.is_contiguous() and index_t.shape[-1] == self.rows
+        columns = index_t.numel() // self.rows
+        st = stream if stream is not None else torch.cuda.current_stream(index_t.device)
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous()
+            assert self.comm_world <= 0 or out.numel() == self.comm_world * index_t.numel()
+        sent = C.c_int64(0)
+        self._chk(self._lib.emspec_gather_columns(self._h, C.c_void_p(index_t.data_ptr()), columns, root,
+                                                  C.c_void_p(out.data_ptr()) if out is not None else None,
+                                                  GATHER_LOOPBACK if loopback else 0, C.c_void_p(st.cuda_stream), C.byref(sent)))
+        return int(sent.value)
+
+    def wire_pack(self, index_t, wire_t, stream=None, want_size=True):
+        """index_t uint8 CUDA [columns, rows] -> wire_t (uint8 CUDA, >= wire_bound bytes); returns the image size."""
+        import torch
+        columns = index_t.numel() // self.rows
+        assert wire_t.numel() >= wire_bound(columns, self.rows)
+        st = stream if stream is not None else torch.cuda.current_stream(index_t.device)
+        n = C.c_int64(-1)
+        self._chk(self._lib.emspec_wire_pack(self._h, C.c_void_p(index_t.data_ptr()), columns, C.c_void_p(wire_t.data_ptr()),
+                                             C.byref(n) if want_size else None, C.c_void_p(st.cuda_stream)))
+        return int(n.value)
+
+    def wire_unpack(self, wire_t, wire_bytes, out_t, stream=None):
+        import torch
+        columns = out_t.numel() // self.rows
+        st = stream if stream is not None else torch.cuda.current_stream(out_t.device)
+        self._chk(self._lib.emspec_wire_unpack(self._h, C.c_void_p(wire_t.data_ptr()), wire_bytes, columns,
+                                               C.c_void_p(out_t.data_ptr()), C.c_void_p(st.cuda_stream)))
 
     # -- parity dump ------------------------------------------------------------
     def parity_dump(self, pcm, n, hop, reassign=True, frame0=0, nframes=None):

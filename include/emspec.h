@@ -43,7 +43,8 @@ typedef enum emspec_status {
     EMSPEC_ERR_NO_DEVICE = -2,     /* no HIP device, or not gfx950 */
     EMSPEC_ERR_HIP = -3,           /* a HIP runtime call failed (message has the HIP error) */
     EMSPEC_ERR_OUT_OF_MEMORY = -4,
-    EMSPEC_ERR_STATE = -5          /* call sequence error (e.g. N/hop changed mid-stream without reset) */
+    EMSPEC_ERR_STATE = -5,         /* call sequence error (e.g. N/hop changed mid-stream without reset) */
+    EMSPEC_ERR_COMM = -6           /* an RCCL call failed, or the ranks of a gather disagree (message has the detail) */
 } emspec_status;
 
 /* Output selection bits for emspec_out / emspec_out_device. */
@@ -237,6 +238,59 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
                               int64_t frame0, int64_t nframes,
                               float* power_dev, int32_t* col_dev, int32_t* row_dev,
                               void* hip_stream);
+
+/*
+ * ---- Multi-GPU: shard the streams, gather the finished columns (BASELINE.json north_star: "many independent
+ * audio streams shard embarrassingly across the 8 GPUs of one node with a single RCCL gather over xGMI to collect
+ * finished columns").  The reference has no GPU path and no collectives: [BUILD-DEFINED].
+ *
+ * One process (or thread) per GPU, each with its own engine.  The host splits the streams into equal shards, every
+ * rank runs emspec_batch_device on its shard (no exchange during compute), then all ranks call
+ * emspec_gather_columns: the palette-index columns (uint8, 1 byte per cell - the float32 dB columns stay on the
+ * producing GPU) of every rank arrive on `root` as gathered[world][columns][rows], rank-major.
+ *
+ * Rank 0 obtains an id with emspec_comm_unique_id and hands its 128 bytes to the other ranks by whatever channel
+ * the host has (Node: IPC / a file; Python: torch.distributed's store); every rank then calls emspec_comm_init
+ * (collective: returns when all `world` ranks have called it).  The communicator lives as long as the engine.
+ */
+#define EMSPEC_COMM_ID_BYTES 128
+int emspec_comm_unique_id(uint8_t* id_out /* [EMSPEC_COMM_ID_BYTES] */);
+int emspec_comm_init(emspec_engine* e, const uint8_t* id /* [EMSPEC_COMM_ID_BYTES] */, int32_t rank, int32_t world);
+int emspec_comm_destroy(emspec_engine* e);
+int32_t emspec_comm_rank(const emspec_engine* e);    /* -1 without a communicator */
+int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator */
+
+/*
+ * Collective over the engine's communicator.  index_dev: this rank's finished palette-index columns
+ * [columns][rows] on its device (columns = streams * columns-per-stream of the shard; the same on every rank).
+ * gathered_dev (root only; ignored elsewhere): [world][columns][rows] on the root's device.
+ * xGMI is point-to-point - each rank reaches the root over one link - so the columns travel as a lossless packed
+ * image (bit mask of the non-zero cells + their indices; emspec_wire_* below) and are expanded on the root.
+ * The call enqueues everything on hip_stream and synchronises that stream ONCE (the packed sizes differ per rank
+ * and must be known on the host before the transfers can be posted): enqueue the next chunk's
+ * emspec_batch_device on another stream BEFORE calling it, and the gather overlaps that compute.
+ * *wire_bytes_sent (optional) receives the size of this rank's packed image (0 on the root).
+ * flags: EMSPEC_GATHER_LOOPBACK makes the root's own columns take the wire as well (self send/recv; exercising
+ * the whole path on a single GPU).
+ */
+#define EMSPEC_GATHER_LOOPBACK 1u
+int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t columns, int32_t root,
+                          uint8_t* gathered_dev, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent);
+
+/*
+ * The wire image by itself, for hosts that bring their own transport: header (32 B) + ceil(rows/32) mask words
+ * per column + the non-zero indices (column-major, rows ascending), see em-spec_amd/csrc/pack.hip.inc.
+ * emspec_wire_bound: capacity a destination needs for `columns` columns (-1 on invalid arguments).
+ * emspec_wire_pack:  index_dev [columns][rows] -> wire_dev; *wire_bytes (optional) = the image size (reading it
+ *                    synchronises hip_stream; pass NULL to stay asynchronous).
+ * emspec_wire_unpack: validates the header against this engine (rows) and `columns`, then expands.
+ * All pointers are device pointers on the engine's device; at most 2^32 cells per call.
+ */
+int64_t emspec_wire_bound(int64_t columns, int32_t rows);
+int emspec_wire_pack(emspec_engine* e, const uint8_t* index_dev, int64_t columns, uint8_t* wire_dev,
+                     int64_t* wire_bytes, void* hip_stream);
+int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_bytes, int64_t columns,
+                       uint8_t* index_dev, void* hip_stream);
 
 /* Copy out the tables the kernels use for (n): row edges in bin units
  * (rows+1 floats) and the twiddle table (n/2 complex = n floats, re,im

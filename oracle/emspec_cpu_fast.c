@@ -1,0 +1,263 @@
+/*
+ * emspec_cpu_fast.c — a competent CPU implementation of the hot path, for the cpu_baseline leg of bench.py.
+ *
+ * TEST INFRASTRUCTURE ONLY (same rules as emspec_oracle.h): nothing in the product may link or call this.
+ * PARITY UNPINNED: the reference's own CPU path is private (/root/reference/README.md:73); this is a stand-in
+ * ("kind": "port") that runs the SAME algorithm as the HIP kernels (one packed complex FFT of
+ * x + j*ramp*x, conjugate split, spectral Hann stencils, reassignment, log-frequency rows, dB + palette index) the
+ * way one would write it for a CPU:
+ *   - Stockham autosort radix-4 FFT (a radix-2 tail for odd log2 N), split re/im arrays, unit-stride inner loops that
+ *     gcc vectorises with -O3 -march=native (AVX2 / AVX-512 on the GPU box's host);
+ *   - per-bin stage in one pass over the spectrum, row found through a fine index table + exact edge compares;
+ *   - the histogram is a (2D+1)-column ring per stream that stays in L1/L2; a finished column is converted to dB
+ *     with a vectorisable log2 polynomial (|error| < 2e-7 in log2, i.e. < 1e-5 dB);
+ *   - OpenMP over streams, threads bound to cores (OMP_PROC_BIND=close, OMP_PLACES=cores set by the caller).
+ * It is NOT bit-identical to the float32 bit model (different butterfly grouping); tests/test_oracle.py checks it
+ * against the bit model at the test tolerance (dB within 1e-3, palette index within 1 on < 0.1 % of cells).
+ */
+#include "emspec_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI 3.14159265358979323846
+
+typedef struct {
+    int n, log2n, R, D, slots, hop, reassign;
+    int npass;            /* radix-4 passes; +1 radix-2 pass when log2n is odd */
+    float* twr; float* twi;   /* per pass: w1,w2,w3 tables, n1 entries each, concatenated */
+    size_t* twoff;        /* offset of each pass's tables */
+    float* ebin;          /* R+1 row edges in bin units */
+    int* rowtab; int tabsub; int tablen;   /* row hint per 1/tabsub bin */
+    float tscale, pfloor_abs;
+    float scale, lo, inv_range, gate;
+} fplan;
+
+static int ilog2i(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
+static void* amalloc(size_t bytes) { return aligned_alloc(64, (bytes + 63) & ~(size_t)63); }
+
+static int fplan_init(fplan* p, const eo_cfg* c) {
+    memset(p, 0, sizeof(*p));
+    p->n = c->n; p->log2n = ilog2i(c->n); p->R = c->rows; p->hop = c->hop; p->reassign = c->reassign;
+    p->D = c->reassign ? (c->n + 2 * c->hop - 1) / (2 * c->hop) : 0;
+    p->slots = 2 * p->D + 1;
+    p->npass = p->log2n / 2;
+    /* twiddles per radix-4 pass: m = n, n/4, ... ; n1 = m/4 */
+    size_t total = 0;
+    p->twoff = (size_t*)malloc(sizeof(size_t) * (p->npass + 1));
+    for (int ps = 0, m = c->n; ps < p->npass; ++ps, m >>= 2) { p->twoff[ps] = total; total += 3 * (size_t)(m / 4); }
+    p->twr = (float*)malloc(sizeof(float) * (total + 16)); p->twi = (float*)malloc(sizeof(float) * (total + 16));
+    for (int ps = 0, m = c->n; ps < p->npass; ++ps, m >>= 2) {
+        int n1 = m / 4;
+        for (int k = 1; k <= 3; ++k)
+            for (int q = 0; q < n1; ++q) {
+                double a = -2.0 * PI * (double)k * (double)q / (double)m;
+                p->twr[p->twoff[ps] + (size_t)(k - 1) * n1 + q] = (float)cos(a);
+                p->twi[p->twoff[ps] + (size_t)(k - 1) * n1 + q] = (float)sin(a);
+            }
+    }
+    p->ebin = (float*)malloc(sizeof(float) * (c->rows + 1));
+    eo_tables(c, NULL, p->ebin);
+    /* row hint table: rowtab[i] = row of bin coordinate i / tabsub (largest r with ebin[r] <= x), clamped to [0,R-1] */
+    p->tabsub = 8; p->tablen = (c->n / 2 + 2) * p->tabsub;
+    p->rowtab = (int*)malloc(sizeof(int) * p->tablen);
+    int r = 0;
+    for (int i = 0; i < p->tablen; ++i) {
+        float x = (float)i / (float)p->tabsub;
+        while (r + 1 < c->rows && p->ebin[r + 1] <= x) ++r;
+        p->rowtab[i] = r;
+    }
+    p->tscale = (float)((double)c->n / 2.0 / (double)c->hop);
+    double pk = (double)c->n / 4.0;
+    p->pfloor_abs = (float)((double)c->power_floor * pk * pk);
+    double nn = (double)c->n;
+    p->scale = (float)(32.0 / (3.0 * nn * nn) * (double)c->gain * (double)c->gain);
+    p->lo = c->db_top - c->db_range; p->inv_range = (float)(1.0 / (double)c->db_range); p->gate = c->gate_db;
+    return 0;
+}
+static void fplan_free(fplan* p) { free(p->twr); free(p->twi); free(p->twoff); free(p->ebin); free(p->rowtab); }
+
+/* Stockham autosort FFT, decimation in frequency, radix 4 (+ one radix-2 pass).  x -> result in xr/xi (ping-pong with yr/yi). */
+static void fft_stockham(const fplan* p, float* restrict xr, float* restrict xi, float* restrict yr, float* restrict yi) {
+    int n = p->n, s = 1, m = n;
+    float *ar = xr, *ai = xi, *br = yr, *bi = yi;
+    for (int ps = 0; ps < p->npass; ++ps, m >>= 2, s <<= 2) {
+        const int n1 = m / 4;
+        const float* w1r = p->twr + p->twoff[ps]; const float* w1i = p->twi + p->twoff[ps];
+        const float *w2r = w1r + n1, *w2i = w1i + n1, *w3r = w2r + n1, *w3i = w2i + n1;
+        if (s >= 8) {
+            for (int q = 0; q < n1; ++q) {
+                const float c1 = w1r[q], s1 = w1i[q], c2 = w2r[q], s2 = w2i[q], c3 = w3r[q], s3 = w3i[q];
+                const float *a0r = ar + (size_t)s * q, *a0i = ai + (size_t)s * q;
+                const float *a1r = a0r + (size_t)s * n1, *a1i = a0i + (size_t)s * n1;
+                const float *a2r = a1r + (size_t)s * n1, *a2i = a1i + (size_t)s * n1;
+                const float *a3r = a2r + (size_t)s * n1, *a3i = a2i + (size_t)s * n1;
+                float *o0r = br + (size_t)s * 4 * q, *o0i = bi + (size_t)s * 4 * q;
+                float *o1r = o0r + s, *o1i = o0i + s, *o2r = o1r + s, *o2i = o1i + s, *o3r = o2r + s, *o3i = o2i + s;
+#pragma omp simd
+                for (int t = 0; t < s; ++t) {
+                    float xar = a0r[t], xai = a0i[t], xbr = a1r[t], xbi = a1i[t], xcr = a2r[t], xci = a2i[t], xdr = a3r[t], xdi = a3i[t];
+                    float t0r = xar + xcr, t0i = xai + xci, t1r = xar - xcr, t1i = xai - xci;
+                    float t2r = xbr + xdr, t2i = xbi + xdi, t3r = xbr - xdr, t3i = xbi - xdi;
+                    o0r[t] = t0r + t2r; o0i[t] = t0i + t2i;
+                    float u1r = t1r + t3i, u1i = t1i - t3r;     /* a - j b - c + j d */
+                    float u2r = t0r - t2r, u2i = t0i - t2i;
+                    float u3r = t1r - t3i, u3i = t1i + t3r;     /* a + j b - c - j d */
+                    o1r[t] = u1r * c1 - u1i * s1; o1i[t] = u1r * s1 + u1i * c1;
+                    o2r[t] = u2r * c2 - u2i * s2; o2i[t] = u2r * s2 + u2i * c2;
+                    o3r[t] = u3r * c3 - u3i * s3; o3i[t] = u3r * s3 + u3i * c3;
+                }
+            }
+        } else {
+            /* early passes (s = 1, 4): vectorise over q; the strided stores are the price of autosort */
+            for (int t = 0; t < s; ++t) {
+#pragma omp simd
+                for (int q = 0; q < n1; ++q) {
+                    size_t i0 = (size_t)s * q + t, st = (size_t)s * n1;
+                    float xar = ar[i0], xai = ai[i0], xbr = ar[i0 + st], xbi = ai[i0 + st];
+                    float xcr = ar[i0 + 2 * st], xci = ai[i0 + 2 * st], xdr = ar[i0 + 3 * st], xdi = ai[i0 + 3 * st];
+                    float t0r = xar + xcr, t0i = xai + xci, t1r = xar - xcr, t1i = xai - xci;
+                    float t2r = xbr + xdr, t2i = xbi + xdi, t3r = xbr - xdr, t3i = xbi - xdi;
+                    size_t o = (size_t)s * 4 * q + t;
+                    br[o] = t0r + t2r; bi[o] = t0i + t2i;
+                    float u1r = t1r + t3i, u1i = t1i - t3r, u2r = t0r - t2r, u2i = t0i - t2i, u3r = t1r - t3i, u3i = t1i + t3r;
+                    br[o + s] = u1r * w1r[q] - u1i * w1i[q]; bi[o + s] = u1r * w1i[q] + u1i * w1r[q];
+                    br[o + 2 * s] = u2r * w2r[q] - u2i * w2i[q]; bi[o + 2 * s] = u2r * w2i[q] + u2i * w2r[q];
+                    br[o + 3 * s] = u3r * w3r[q] - u3i * w3i[q]; bi[o + 3 * s] = u3r * w3i[q] + u3i * w3r[q];
+                }
+            }
+        }
+        float* tr = ar; ar = br; br = tr; tr = ai; ai = bi; bi = tr;
+    }
+    if (p->log2n & 1) {   /* m == 2: one radix-2 pass, no twiddles */
+#pragma omp simd
+        for (int t = 0; t < s; ++t) {
+            float x0r = ar[t], x0i = ai[t], x1r = ar[t + s], x1i = ai[t + s];
+            br[t] = x0r + x1r; bi[t] = x0i + x1i; br[t + s] = x0r - x1r; bi[t + s] = x0i - x1i;
+        }
+        float* tr = ar; ar = br; br = tr; tr = ai; ai = bi; bi = tr;
+    }
+    if (ar != xr) { memcpy(xr, ar, sizeof(float) * n); memcpy(xi, ai, sizeof(float) * n); }
+}
+
+/* log2 of a positive normal float: exponent + degree-8 polynomial of the mantissa in [1,2) */
+static inline float fast_log2f(float x) {
+    union { float f; unsigned u; } v = { x };
+    int e = (int)(v.u >> 23) - 127;
+    v.u = (v.u & 0x007FFFFFu) | 0x3F800000u;
+    float m = v.f - 1.0f;   /* [0,1) */
+    /* Chebyshev fit of log2(1+m)/m on [0,1], degree 8 (float32 Horner: |error| < 2.1e-7 in log2, 6.3e-7 dB) */
+    float pl = 0.007579062134f;
+    pl = pl * m - 0.04268687218f;
+    pl = pl * m + 0.1130514294f;
+    pl = pl * m - 0.1972846985f;
+    pl = pl * m + 0.2757194042f;
+    pl = pl * m - 0.3584284186f;
+    pl = pl * m + 0.4806954563f;
+    pl = pl * m - 0.7213402987f;
+    pl = pl * m + 1.442695022f;
+    return (float)e + pl * m;
+}
+
+static void finalize_col(const fplan* p, float* restrict cells, float* db, uint8_t* index) {
+    const int R = p->R;
+    const float k10 = 3.0102999566398120f;
+#pragma omp simd
+    for (int r = 0; r < R; ++r) {
+        float d = k10 * fast_log2f(cells[r] * p->scale + 1e-20f);
+        float v = (d - p->lo) * p->inv_range;
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        v = d < p->gate ? 0.0f : v;
+        if (db) db[r] = d;
+        if (index) index[r] = (uint8_t)(int)(v * 255.0f + 0.5f);
+        cells[r] = 0.0f;
+    }
+}
+
+static void stream_fast(const fplan* p, const float* pcm, int64_t L, float* db, uint8_t* index) {
+    const int n = p->n, half = n / 2, R = p->R, D = p->D, slots = p->slots;
+    const int64_t C = L >= n ? (L - n) / p->hop + 1 : 0;
+    float* buf = (float*)amalloc(sizeof(float) * 4 * (size_t)n);
+    float *xr = buf, *xi = buf + n, *yr = buf + 2 * n, *yi = buf + 3 * n;
+    float* spec = (float*)amalloc(sizeof(float) * 4 * (size_t)(half + 8));   /* Yr, Yi, Tr, Ti for k = -1 .. half+1 */
+    float *Yr = spec, *Yi = spec + (half + 8), *Tr = spec + 2 * (half + 8), *Ti = spec + 3 * (half + 8);
+    float* ring = (float*)amalloc(sizeof(float) * (size_t)slots * R);
+    float* ramp = (float*)amalloc(sizeof(float) * n);
+    memset(ring, 0, sizeof(float) * (size_t)slots * R);
+    const float rs = 2.0f / (float)n;
+    for (int i = 0; i < n; ++i) ramp[i] = (float)(i - half) * rs;
+    const float Df = (float)D, sub = (float)p->tabsub;
+    for (int64_t j = 0; j < C; ++j) {
+        const float* x = pcm + j * p->hop;
+#pragma omp simd
+        for (int i = 0; i < n; ++i) { xr[i] = x[i]; xi[i] = x[i] * ramp[i]; }
+        fft_stockham(p, xr, xi, yr, yi);
+        /* conjugate split, stored at index k+1 for k = -1 .. half+1 */
+        Yr[0] = xr[n - 1] + xr[1]; Yi[0] = xi[n - 1] - xi[1]; Tr[0] = xi[n - 1] + xi[1]; Ti[0] = xr[1] - xr[n - 1];
+        Yr[1] = xr[0] + xr[0]; Yi[1] = 0.0f; Tr[1] = xi[0] + xi[0]; Ti[1] = 0.0f;
+#pragma omp simd
+        for (int k = 1; k <= half; ++k) {
+            float ar = xr[k], ai = xi[k], br = xr[n - k], bi = xi[n - k];
+            Yr[k + 1] = ar + br; Yi[k + 1] = ai - bi; Tr[k + 1] = ai + bi; Ti[k + 1] = br - ar;
+        }
+        { int k = half + 1; float ar = xr[k], ai = xi[k], br = xr[n - k], bi = xi[n - k];
+          Yr[k + 1] = ar + br; Yi[k + 1] = ai - bi; Tr[k + 1] = ai + bi; Ti[k + 1] = br - ar; }
+        /* per-bin stages: power, reassignment, cell */
+        const int sj = (int)(j % slots);   /* ring slot of column j */
+        for (int k = 0; k < half; ++k) {   /* the Nyquist bin never reaches the histogram (k-hat = N/2 >= ebin[R]) */
+            float Ar = (Yr[k + 1] + Yr[k + 1]) - (Yr[k] + Yr[k + 2]), Ai = (Yi[k + 1] + Yi[k + 1]) - (Yi[k] + Yi[k + 2]);
+            float den = Ar * Ar + Ai * Ai;
+            float P = den * 0.015625f;
+            if (!(P >= p->pfloor_abs) || !(P <= 3.0e38f)) continue;
+            float kh = (float)k;
+            int col = sj;
+            if (p->reassign) {
+                float Br = (Tr[k + 1] + Tr[k + 1]) - (Tr[k] + Tr[k + 2]), Bi = (Ti[k + 1] + Ti[k + 1]) - (Ti[k] + Ti[k + 2]);
+                float Dr = Yr[k] - Yr[k + 2], Di = Yi[k] - Yi[k + 2];
+                float inv = 1.0f / den;
+                float cf = floorf((Br * Ar + Bi * Ai) * inv * p->tscale + 0.5f);
+                if (!(fabsf(cf) <= Df)) continue;
+                int64_t cabs = j + (int64_t)cf;
+                if (cabs < 0 || cabs >= C) continue;
+                col = sj + (int)cf;
+                col += col < 0 ? slots : 0; col -= col >= slots ? slots : 0;
+                kh += (Dr * Ar + Di * Ai) * inv;
+            }
+            if (!(kh >= p->ebin[0]) || !(kh < p->ebin[R])) continue;
+            int ti = (int)(kh * sub);
+            int r = p->rowtab[ti];                      /* hint: row of floor(kh*sub)/sub <= kh */
+            while (r + 1 < R && p->ebin[r + 1] <= kh) ++r;
+            ring[(size_t)col * R + r] += P;
+        }
+        /* column j-D is complete */
+        if (j - D >= 0) {
+            int sl = (int)((j - D) % slots);
+            finalize_col(p, ring + (size_t)sl * R, db ? db + (size_t)(j - D) * R : NULL, index ? index + (size_t)(j - D) * R : NULL);
+        }
+    }
+    for (int64_t c = (C - D > 0 ? C - D : 0); c < C; ++c) {
+        int sl = (int)(c % slots);
+        finalize_col(p, ring + (size_t)sl * R, db ? db + (size_t)c * R : NULL, index ? index + (size_t)c * R : NULL);
+    }
+    free(buf); free(spec); free(ring); free(ramp);
+}
+
+/* pcm[S][L] -> db / index [S][C][R] (either may be NULL).  threads <= 0: all. */
+int eo_fast_batch(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, float* db, uint8_t* index, int32_t threads) {
+    if (!c || !pcm || c->n < 64 || (c->n & (c->n - 1)) || c->hop < 1 || c->rows < 1) return -1;
+    fplan p;
+    if (fplan_init(&p, c)) return -3;
+    const int64_t C = L >= c->n ? (L - c->n) / c->hop + 1 : 0;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1) proc_bind(close)
+#endif
+    for (int s = 0; s < S; ++s)
+        stream_fast(&p, pcm + (size_t)s * L, L, db ? db + (size_t)s * C * c->rows : NULL,
+                    index ? index + (size_t)s * C * c->rows : NULL);
+    fplan_free(&p);
+    return 0;
+}

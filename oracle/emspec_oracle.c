@@ -38,6 +38,13 @@ static void make_twiddle(int n, float* tw) {
         tw[2 * q] = (float)cos(a);
         tw[2 * q + 1] = (float)(-sin(a));
     }
+    /* second quarter by symmetry, tw[q + N/4] = -j tw[q] = (tw[q].im, -tw[q].re): the values cos/sin give anyway
+     * (an identity with a correctly rounded libm, checked by tests/test_oracle.py), stated so that it is a property
+     * of the table */
+    for (int q = 0; q < n / 4; ++q) {
+        tw[2 * (q + n / 4)] = tw[2 * q + 1];
+        tw[2 * (q + n / 4) + 1] = -tw[2 * q];
+    }
     /* the quarter-turn entry is exact, so "multiply by tw[N/4]" == "(di,-dr)" */
     tw[2 * (n / 4)] = 0.0f;
     tw[2 * (n / 4) + 1] = -1.0f;

@@ -61,6 +61,10 @@ int eo_hist_f32(const eo_cfg* c, const float* pcm, int32_t S, int64_t L,
                 float* hist, int32_t threads);
 int eo_max_threads(void);
 
+/* emspec_cpu_fast.c: the same pipeline written for speed on a CPU (Stockham radix-4 FFT, ring histogram, vectorised
+ * dB), for bench.py's cpu_baseline leg.  Not bit-identical to the bit model; checked against it at the test tolerance. */
+int eo_fast_batch(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, float* db, uint8_t* index, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

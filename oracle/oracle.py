@@ -34,8 +34,8 @@ def make_cfg(n, hop, reassign=True, **kw):
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "emspec_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("emspec_oracle.c", "emspec_cpu_fast.c", "emspec_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libemspec_oracle.so"])
     return _SO
 
@@ -136,6 +136,19 @@ def batch_f32(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
 
 def max_threads():
     return lib().eo_max_threads()
+
+
+def fast_batch(cfg, pcm, want=("db", "index"), threads=0):
+    """The CPU port written for speed (emspec_cpu_fast.c): same pipeline, not bit-identical to the bit model."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    S, L = pcm.shape
+    Cn = num_columns(L, cfg.n, cfg.hop)
+    db = np.empty((S, Cn, cfg.rows), np.float32) if "db" in want else None
+    idx = np.empty((S, Cn, cfg.rows), np.uint8) if "index" in want else None
+    rc = lib().eo_fast_batch(C.byref(cfg), _p(pcm, C.c_float), C.c_int32(S), C.c_int64(L), _p(db, C.c_float),
+                             _p(idx, C.c_uint8), C.c_int32(threads))
+    assert rc == 0, rc
+    return db, idx
 
 
 def postprocess(db, smoothing, agc, cfg, lut=None):

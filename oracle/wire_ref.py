@@ -1,0 +1,51 @@
+"""numpy restatement of the gather's wire image (em-spec_amd/csrc/pack.hip.inc) — TEST INFRASTRUCTURE ONLY.
+
+The reference has no multi-GPU path, so the format is [BUILD-DEFINED]; this file pins the byte layout
+the HIP pack / unpack kernels must produce:
+    header 32 B : u32 magic 'EMW1', u32 rows, u64 columns, u64 payload bytes, 8 B zero
+    masks       : columns x ceil(rows/32) u32 words, bit (r % 32) of word r // 32 set <=> index[r] != 0
+    payload     : the non-zero indices, column after column, rows ascending; zero-padded to a multiple of 16 B
+"""
+import numpy as np
+
+MAGIC = 0x31574D45
+
+
+def mask_words(rows):
+    return (rows + 31) // 32
+
+
+def bound(columns, rows):
+    return 32 + columns * (mask_words(rows) * 4 + rows) + 16
+
+
+def pack(index):
+    """index: uint8 [columns][rows] -> uint8 wire image (exact size)."""
+    index = np.ascontiguousarray(index, np.uint8)
+    columns, rows = index.shape
+    mw = mask_words(rows)
+    nz = index != 0
+    bits = np.zeros((columns, mw * 32), bool)
+    bits[:, :rows] = nz
+    words = (bits.reshape(columns, mw, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+    payload = index[nz]                      # row-major order = column after column, rows ascending
+    pad = (-payload.size) % 16
+    hdr = np.zeros(8, np.uint32)
+    hdr[0], hdr[1] = MAGIC, rows
+    hdr[2], hdr[3] = columns & 0xFFFFFFFF, columns >> 32
+    hdr[4], hdr[5] = payload.size & 0xFFFFFFFF, payload.size >> 32
+    return np.concatenate([hdr.view(np.uint8), words.reshape(-1).view(np.uint8), payload, np.zeros(pad, np.uint8)])
+
+
+def unpack(wire, columns, rows):
+    wire = np.ascontiguousarray(wire, np.uint8)
+    hdr = wire[:32].view(np.uint32)
+    assert hdr[0] == MAGIC and hdr[1] == rows and (int(hdr[2]) | int(hdr[3]) << 32) == columns
+    npay = int(hdr[4]) | int(hdr[5]) << 32
+    mw = mask_words(rows)
+    words = wire[32:32 + columns * mw * 4].view(np.uint32).reshape(columns, mw)
+    bits = ((words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool).reshape(columns, mw * 32)[:, :rows]
+    assert int(bits.sum()) == npay
+    out = np.zeros((columns, rows), np.uint8)
+    out[bits] = wire[32 + columns * mw * 4: 32 + columns * mw * 4 + npay]
+    return out

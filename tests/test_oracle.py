@@ -132,6 +132,40 @@ def test_tables_and_lut():
     assert tuple(lut[64][:3]) == (80, 0, 80) or abs(int(lut[64][0]) - 80) <= 1
 
 
+@pytest.mark.parametrize("n", [256, 1024, 4096, 16384])
+def test_twiddle_table_is_what_libm_gives_and_quarter_turn_symmetric(n):
+    """tw[q] = (cos, -sin)(2 pi q / N) evaluated in double and rounded once; the second quarter is
+    written by symmetry (tw[q + N/4] = (tw[q].im, -tw[q].re)), which must be an identity on the libm values so that the
+    golden vectors and every earlier result stay bit-identical."""
+    tw, _ = O.tables(O.make_cfg(n, 64, True))
+    q = np.arange(n // 2)
+    a = 2.0 * np.pi * q.astype(np.float64) / n
+    direct = np.stack([np.cos(a), -np.sin(a)], axis=1).astype(np.float32)
+    direct[n // 4] = (0.0, -1.0)
+    assert np.array_equal(tw.reshape(-1, 2), direct)
+    c, s = tw[0::2], tw[1::2]
+    assert np.array_equal(c[n // 4:], s[:n // 4]) and np.array_equal(s[n // 4 + 1:], -c[1:n // 4])
+
+
+@pytest.mark.parametrize("n,hop,reassign", [(4096, 256, True), (1024, 256, False), (16384, 512, True), (2048, 128, True),
+                                            (8192, 1024, True)])
+def test_cpu_fast_port_agrees_with_bit_model(n, hop, reassign):
+    """bench.py's cpu_baseline port (emspec_cpu_fast.c: Stockham radix-4 FFT, ring histogram, polynomial log2) runs the
+    same pipeline as the bit model.  It is not bit-identical (other butterfly grouping), so a bin whose coordinate sits on
+    a cell edge may land next door (rare), and cells near the display floor carry either FFT's rounding noise."""
+    frames = 60
+    pcm = synth.streams(2, n + hop * (frames - 1) + 13)
+    cfg = O.make_cfg(n, hop, reassign)
+    odb, _, oidx = O.batch_f32(cfg, pcm, want=("db", "index"))
+    fdb, fidx = O.fast_batch(cfg, pcm, threads=2)
+    d = np.abs(fdb - odb)
+    strong = odb > -60.0          # 20 dB above the display floor: float32 rounding of either FFT is far below these cells
+    shown = odb > -80.0           # the displayed range (gate = -80 dB); a bin on a cell edge may land next door
+    assert np.percentile(d[strong], 99) < 1e-4 and np.mean(d[strong] > 1e-3) < 5e-3
+    assert np.mean(d[shown] > 1e-3) < 1e-2
+    assert np.mean(fidx != oidx) < 1e-3
+
+
 def test_batch_pipeline_consistency():
     """eo_batch_f32 == scatter of eo_frames_f32 + dB map, including edge drops and empty cells."""
     n, hop, frames = 1024, 256, 20
