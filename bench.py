@@ -5,13 +5,18 @@ A "step" is one pass of the hot path over one batch of synthetic audio that is
 already resident in HBM: every rank turns its 64 streams x 2^22 samples
 (BASELINE.json configs[2]; configs[3] at N=8) into 64 x 16,369 finished columns
 (float32 dB + uint8 palette index per cell).  For N > 1 the streams shard
-across ranks with no data-path exchange; the only collective is the RCCL
-gather of the finished palette-index columns to rank 0 (north_star), issued
-per stream-chunk on a side stream so it overlaps the next chunk's compute.
+across ranks with no data-path exchange; the only collective is the gather of
+the finished palette-index columns to rank 0 (north_star), done by libemspec
+itself over RCCL (emspec_gather_columns: packed wire image, grouped send/recv)
+per stream-chunk on a side stream, so it overlaps the next chunk's compute.
 
-Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md §6).
+Prints ONE JSON line on rank 0 (contract: see the task statement / DESIGN.md §5, §6).
+At N = 1 the line also carries `configs` (the other named BASELINE configs measured beside the
+headline), `roofline_compute` (the bounds the kernel really sits under) and `cpu_baseline`.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -25,7 +30,36 @@ for _p in (ROOT, os.path.join(ROOT, "em-spec_amd"), os.path.join(ROOT, "oracle")
 import numpy as np
 import torch
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+SIMDS = 256 * 4
+# algorithmic flops per column (1.5 complex FFTs + per-bin + dB), the contract figure
+FLOPS_PER_COLUMN = {1024: 0.10e6, 2048: 0.21e6, 4096: 0.45e6, 8192: 0.93e6, 16384: 1.9e6}
+
+
+def sources_sha():
+    """sha1 over the kernel / C-ABI sources: profile-derived numbers are only quoted when they were taken on these."""
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "em-spec_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "**", "*"), recursive=True)):
+        if os.path.isfile(f) and f.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(os.path.relpath(f, base).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_for(workload):
+    """Committed rocprofv3 summary of this workload (profiles/*_<workload>.json, written by tools/profile_json.py),
+    newest first; returns (dict, fresh) where fresh says the kernels are unchanged since it was taken."""
+    sha = sources_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}.json")))[::-1]:
+        try:
+            d = json.load(open(f))
+            d["file"] = os.path.relpath(f, ROOT)
+            return d, d.get("sources_sha") == sha
+        except Exception:
+            continue
+    return None, False
 
 
 def _lsr(z, k):
@@ -78,25 +112,58 @@ def synth_device(S, L, first_stream, device, fs=48000.0):
     return out
 
 
-def cpu_baseline(n, hop, seconds_target=12.0):
-    """Time the CPU oracle (float32 bit model, oracle/emspec_oracle.c) on a bounded sample of the
-    same workload, all host cores (OpenMP over streams)."""
+def host_cores():
+    """(cores this process may use, physical cores visible, logical CPUs visible): SMT siblings count once, and a
+    cgroup CPU quota (the GPU box grants 16 CPUs of a 128-core host) caps the number of threads worth starting."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cpus = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        p = f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"
+        seen.add(open(p).read().strip() if os.path.exists(p) else str(c))
+    phys = max(1, len(seen))
+    quota = phys
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except Exception:
+        pass
+    return min(phys, quota), phys, len(cpus)
+
+
+_HOST_CORES = host_cores()      # before anything loads an OpenMP runtime that might re-bind this thread
+
+
+def cpu_baseline(n, hop, seconds_target=8.0):
+    """Time the CPU port of the same pipeline (oracle/emspec_cpu_fast.c: Stockham radix-4 FFT, ring histogram per
+    stream, vectorised dB; gcc -O3 -march=native, OpenMP proc_bind(close)) on a bounded sample of the same workload:
+    one thread, then one thread per physical core.  A stand-in ("port"): the reference's CPU path is private."""
     import oracle as O
     from emspec import synth
-    cores = O.max_threads()
+    cores, phys, logical = _HOST_CORES
+    cores = max(1, min(cores, O.max_threads()))
     cfg = O.make_cfg(n, hop, True)
-    # calibrate on a small run, then size the sample for ~seconds_target
-    probe = synth.streams(cores, n + hop * 127)
-    t0 = time.perf_counter(); O.batch_f32(cfg, probe, want=("db", "index"), threads=cores); dt = time.perf_counter() - t0
-    rate = cores * 128 / dt
-    cols_per_stream = int(max(256, min(8192, rate * seconds_target / cores)))
-    L = n + hop * (cols_per_stream - 1)
-    base = synth.streams(1, L)
-    pcm = np.stack([np.roll(base[0], 977 * s) for s in range(cores)])
-    t0 = time.perf_counter(); O.batch_f32(cfg, pcm, want=("db", "index"), threads=cores); dt = time.perf_counter() - t0
-    return {"value": cores * cols_per_stream / dt, "unit": "columns/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} streams x {cols_per_stream} columns (N={n}, hop={hop}, reassign on), "
-                      f"oracle float32 bit model, OpenMP {cores} threads, {dt:.1f} s"}
+    # one thread: calibrate on a short run, then ~seconds_target/3 of work
+    probe = synth.streams(1, n + hop * 255)
+    t0 = time.perf_counter(); O.fast_batch(cfg, probe, threads=1); dt = time.perf_counter() - t0
+    rate1 = 256 / dt
+    c1 = int(max(512, min(1 << 16, rate1 * seconds_target / 3)))
+    base = synth.streams(1, n + hop * (c1 - 1))
+    t0 = time.perf_counter(); O.fast_batch(cfg, base, threads=1); dt1 = time.perf_counter() - t0
+    per_core = c1 / dt1
+    # all cores: one stream per core, each the same length (rolled copies: same statistics, distinct data)
+    ca = int(max(512, min(c1, per_core * seconds_target * 2 / 3)))
+    La = n + hop * (ca - 1)
+    pcm = np.stack([np.roll(base[0, :La], 977 * s) for s in range(cores)])
+    t0 = time.perf_counter(); O.fast_batch(cfg, pcm, threads=cores); dta = time.perf_counter() - t0
+    return {"value": cores * ca / dta, "unit": "columns/s", "cores": cores, "kind": "port",
+            "per_core": per_core, "host_physical_cores": phys, "host_logical_cpus": logical,
+            "sample": f"{cores} streams x {ca} columns on {cores} threads (one per core, OpenMP proc_bind(close); the box's CPU quota) ({dta:.1f} s); one thread: {c1} "
+                      f"columns ({dt1:.1f} s).  N={n}, hop={hop}, reassign on, float32 dB + palette index out; "
+                      f"oracle/emspec_cpu_fast.c (same pipeline as the HIP kernels, Stockham radix-4 FFT, -O3 -march=native)"}
 
 
 def js_baseline(n, hop, seconds=5.0):
@@ -118,7 +185,34 @@ def js_baseline(n, hop, seconds=5.0):
         return None
 
 
+def time_launches(fn, stream, reps):
+    """average HIP-event duration (ms) of reps back-to-back calls of fn on `stream` (after one untimed call)"""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def roofline(cols, bytes_per_col, ms, note=None):
+    ach = cols * bytes_per_col / (ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "bytes_per_column": bytes_per_col, "kernel_ms": ms}
+    if note:
+        d["note"] = note
+    return d
+
+
 def main():
+    # Exactly ONE line may reach stdout (the driver parses it), but RCCL prints a version banner there when a
+    # communicator is created: keep the real stdout for the JSON line and send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -128,10 +222,14 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=22)
     ap.add_argument("--chunks", type=int, default=2, help="stream-chunks per step (gather overlap, N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="N=1: skip the side measurements of the other named configs")
     ap.add_argument("--force-chunks", type=int, default=0, help="N=1: launch per stream-chunk as the N>1 path does (no gather)")
     ap.add_argument("--reassign", type=int, default=1)
+    ap.add_argument("--gather", default="lib", choices=["lib", "torch", "loopback"],
+                    help="lib = libemspec's RCCL gather (default); torch = torch.distributed.gather of raw columns; "
+                         "loopback = N=1 rehearsal: the rank's own columns go through pack + RCCL self send/recv + expand")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (gather via host tensors)")
+                    help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (torch gather via host tensors)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,24 +270,65 @@ def main():
     first_stream, _ = shard.stream_shard(rank, world, world * S)
     pcm = synth_device(S, L, first_stream, dev)
     db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
-    # N>1: two index buffers, so the gather of step k's last chunks overlaps step k+1's first kernels
-    nbuf = 2 if world > 1 else 1
+
+    # ---- gather set-up.  lib: libemspec's own communicator (RCCL), id handed over through torch.distributed.
+    gather_mode, gather_note = "none", None
+    if world > 1:
+        gather_mode = "torch" if (args.gather == "torch" or args.backend == "gloo") else "lib"
+        if gather_mode == "lib":
+            try:
+                shard.comm_setup(eng, rank, world)
+            except Exception as ex:           # keep the run alive on the old path and say so in the line
+                gather_mode, gather_note = "torch", f"libemspec communicator failed ({ex}); fell back to torch.distributed.gather"
+            ok = torch.tensor([1 if gather_mode == "lib" else 0], device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank must be on the same path
+            if int(ok.item()) == 0 and gather_mode == "lib":
+                gather_mode, gather_note = "torch", "another rank could not create the libemspec communicator; torch.distributed.gather"
+    elif args.gather == "loopback":
+        eng.comm_init(emspec.comm_unique_id(), 0, 1)
+        gather_mode = "lib"
+    gathering = gather_mode != "none"
+
+    # N>1: two index buffers, so the gather of step k's last chunk overlaps step k+1's first kernels
+    nbuf = 2 if gathering else 1
     idx_bufs = [torch.empty((S, C, R), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     idx = idx_bufs[0]
-
-    nch = max(1, min(args.chunks, S)) if world > 1 else max(1, min(args.force_chunks, S)) if args.force_chunks else 1
+    nch = max(1, min(args.chunks, S)) if gathering else max(1, min(args.force_chunks, S)) if args.force_chunks else 1
     bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    gathered = None
+    comm_stream = torch.cuda.Stream(device=dev) if gathering else None
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=gdev) for _ in range(world)] for a, b in bounds]
+    gworld = max(world, 1)
+    gathered = None
+    if gathering and rank == 0:
+        if gather_mode == "lib":      # [chunk] -> [world, streams of the chunk, C, R]
+            gathered = [torch.empty((gworld, b - a, C, R), dtype=torch.uint8, device=dev) for a, b in bounds]
+        else:
+            gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=gdev) for _ in range(world)] for a, b in bounds]
 
     cur = torch.cuda.current_stream(dev)
     kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
     sent = [[None] * nch for _ in range(nbuf)]     # per (buffer, chunk): event after its last gather
     nstep = [0]
+    pending = []                                   # (buffer index, chunk index, ready event): computed, not yet gathered
+    wire_bytes = [0, 0]                            # packed bytes this rank sent, columns they carried
+
+    def do_gather(p, ci, ready):
+        a, b = bounds[ci]
+        ibuf = idx_bufs[p]
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            if gather_mode == "lib":
+                # pack + size exchange + send/recv + expand on comm_stream; the call synchronises comm_stream once, while
+                # the next chunk's kernels (already enqueued on the compute stream) keep the GPU busy
+                nb = eng.gather_columns(ibuf[a:b], root=0, out=gathered[ci] if rank == 0 else None, stream=comm_stream,
+                                        loopback=(world == 1))
+                wire_bytes[0] += nb
+                wire_bytes[1] += (b - a) * C if nb else 0
+            else:
+                src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
+                shard.gather_columns_into(src, gathered[ci] if rank == 0 else None, dst=0)
+            sent[p][ci] = torch.cuda.Event()
+            sent[p][ci].record(comm_stream)
 
     def step(timed_i=None):
         p = nstep[0] % nbuf
@@ -203,38 +342,45 @@ def main():
             eng.batch_device(pcm[a:b], n, hop, bool(args.reassign), db=db[a:b], index=ibuf[a:b], stream=cur)
             if timed_i is not None and ci == nch - 1:
                 kev[timed_i][1].record(cur)
-            if world > 1:
+            if gathering:
                 ready = torch.cuda.Event()
                 ready.record(cur)
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(ready)
-                    src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
-                    shard.gather_columns_into(src, gathered[ci] if rank == 0 else None, dst=0)
-                    sent[p][ci] = torch.cuda.Event()
-                    sent[p][ci].record(comm_stream)
+                # gather the PREVIOUS chunk now that this one is enqueued behind it: the host may block in there
+                while pending:
+                    do_gather(*pending.pop(0))
+                pending.append((p, ci, ready))
+
+    def flush():
+        while pending:
+            do_gather(*pending.pop(0))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:
-        # open the point-to-point connections the gather uses before anything is timed (with --warmup 0 the
-        # first gather would otherwise pay for them inside the timed region)
+    if world > 1 and gather_mode == "torch":
+        # open the point-to-point connections the gather uses before anything is timed
         probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
         shard.gather_columns_into(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1 if gathering else 0)):   # the first gather opens RCCL's connections: never timed
         step()
+    flush()
+    wire_bytes[:] = [0, 0]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        wb = torch.tensor(wire_bytes, dtype=torch.float64, device=gdev)
+        dist.all_reduce(wb, op=dist.ReduceOp.SUM)
+        wire_bytes = [float(wb[0].item()), float(wb[1].item())]
 
     if rank == 0:
         cols_per_step = world * S * C
@@ -244,67 +390,87 @@ def main():
         bytes_per_col = 4 * hop + 4 * R + R
         kms = [a.elapsed_time(b) for a, b in kev]           # HIP events on the launch stream
         k_avg_ms = float(np.mean(kms))
-        achieved = S * C * bytes_per_col / (k_avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        if args.workload == "batch64" and S == 64 and args.log2_samples == 22:
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[::-1]:
-                try:
-                    summ = json.load(open(f))["summary"]
-                    traffic, traffic_src = summ["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-                    break
-                except Exception:
-                    pass
-        # second view of the same launch: VALU issue rate against the chip's measured rate.  The instruction
-        # count per launch comes from the committed SQ counters, the chip rate from tools/ubench/valu_rate.hip.
-        valu = None
-        if traffic is not None:
-            try:
-                tag = os.path.basename(traffic_src).split("_")[0]
-                for ln in open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.txt")):
-                    if ln.startswith("SQ_INSTS_VALU"):
-                        insts = float(ln.split()[1])
-                        rate = insts / (k_avg_ms * 1e-3) / 1024          # per SIMD (256 CUs x 4)
-                        valu = {"valu_insts_per_launch": insts, "achieved_per_simd_per_s": rate,
-                                "chip_measured_per_simd_per_s": {"v_fma_f32": 7.4e8, "v_add_f32": 8.7e8},
-                                "frac_range": [rate / 8.7e8, rate / 7.4e8],
-                                "source": f"profiles/{tag}_sq_counters.txt, profiles/{tag}_valu_rate.txt"}
-            except Exception:
-                valu = None
+        rf = roofline(S * C, bytes_per_col, k_avg_ms,
+                      "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / HIP-event duration of "
+                      "the column kernel(s) on the launch stream; PMC traffic: profiles/")
+        rf["algorithmic_bytes_per_launch"] = S * C * bytes_per_col
+        prof, fresh = (None, False)
+        if S == 64 and args.log2_samples == 22:
+            prof, fresh = profile_for(args.workload)
+        rf["traffic"] = prof["hbm_bytes_per_launch"] if (prof and fresh and "hbm_bytes_per_launch" in prof) else None
+        rf["traffic_source"] = (f"{prof['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; sources {prof['sources_sha']}"
+                                f"{'' if fresh else ', STALE: kernels changed since, traffic withheld'})") if prof else None
+        wl = (f"{S} concurrent 48 kHz streams per GPU x 2^{args.log2_samples} samples, FFT {n}, hop {hop}, reassignment "
+              f"{'ON' if args.reassign else 'OFF'}, {R} log-frequency rows, outputs float32 dB + uint8 palette index")
+        if gathering:
+            wl += (f"; gather of the palette-index columns to rank 0 in {nch} overlapped chunks per step by "
+                   + ("libemspec over RCCL (emspec_gather_columns, packed wire image)" if gather_mode == "lib"
+                      else "torch.distributed.gather (raw columns)"))
         line = {
             "metric": "reassigned spectrogram columns/sec (4096-pt, hop 256, 48 kHz)" if n == 4096 else
                       f"reassigned spectrogram columns/sec ({n}-pt, hop {hop}, 48 kHz)",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} concurrent 48 kHz streams per GPU x 2^{args.log2_samples} samples, FFT {n}, "
-                                   f"hop {hop}, reassignment ON, {R} log-frequency rows, outputs float32 dB + uint8 "
-                                   f"palette index" + (f"; RCCL gather of the palette-index columns to rank 0 in "
-                                                       f"{nch} overlapped chunks" if world > 1 else ""),
-                       "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
-                       "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": S * C * bytes_per_col,
-                         "bytes_per_column": bytes_per_col, "kernel_ms": k_avg_ms,
-                         "note": "algorithmic bytes (4*hop in + 4*R dB + R index out) x columns per launch / "
-                                 "HIP-event duration of the column kernel(s) on the launch stream; PMC traffic: profiles/"},
+            "config": {"workload": wl, "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
+                       "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True),
+                       "sources_sha": sources_sha()},
+            "roofline": rf,
         }
-        if valu is not None:
-            line["valu_issue"] = valu
-        if world == 1 and args.workload == "batch64":
-            # BASELINE configs[1] (one stream of 2^22 samples) measured beside the headline, same engine
-            one = pcm[:1].contiguous()
-            for _ in range(3):
-                eng.batch_device(one, n, hop, True, db=db[:1], index=idx[:1], stream=cur)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            reps = 50
-            for _ in range(reps):
-                eng.batch_device(one, n, hop, True, db=db[:1], index=idx[:1], stream=cur)
-            torch.cuda.synchronize(dev)
-            line["config"]["single_stream_columns_per_s"] = C * reps / (time.perf_counter() - t1)
-        if world == 1 and args.workload == "batch64":
+        if gathering:
+            line["gather"] = {"path": gather_mode, "note": gather_note, "chunks_per_step": nch,
+                              "wire_bytes_per_column": (wire_bytes[0] / wire_bytes[1]) if wire_bytes[1] else None,
+                              "raw_bytes_per_column": R}
+        # the bounds this kernel really sits under (it is not HBM-bound: SURVEY.md §8(d) consistency warning)
+        rc = {"flops_per_column": FLOPS_PER_COLUMN.get(n), "flop_note": "SURVEY.md §8(d) algorithmic flops per column",
+              "fp32_peak_tflops": FP32_PEAK_TFLOPS}
+        if rc["flops_per_column"]:
+            tf = rc["flops_per_column"] * (S * C) / (k_avg_ms * 1e-3) / 1e12
+            rc["achieved_tflops"], rc["flop_frac"] = tf, tf / FP32_PEAK_TFLOPS
+        if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
+            # cycle domain: a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md), so the VALU
+            # pipes of 1024 SIMDs offer clock/2 wave-instructions per second each
+            rate = prof["valu_insts_per_column"] * (S * C) / (k_avg_ms * 1e-3)
+            rc["valu_util"] = rate * 2.0 / (SIMDS * prof["clock_ghz"] * 1e9)
+            rc["valu_insts_per_column"] = prof["valu_insts_per_column"]
+            rc["clock_ghz"] = prof["clock_ghz"]
+            rc["clock_note"] = prof.get("clock_note")
+            rc["barrier_wait_share"] = prof.get("wait_any_share")
+            rc["source"] = f"{prof['file']} (SQ counters and clock of the same launch; sources {prof['sources_sha']})"
+        elif prof:
+            rc["valu_util"] = None
+            rc["source"] = f"{prof['file']} is stale (kernels changed since): counter-derived fields withheld"
+        line["roofline_compute"] = rc
+
+        if world == 1 and args.workload == "batch64" and not args.no_configs:
+            # ---- the other named BASELINE configs, measured beside the headline on the same engine and input
+            cfgs = {}
+
+            def measure(name, Sx, Lx, nx, hx, re, reps):
+                Cx = emspec.num_columns(Lx, nx, hx)
+                px = pcm[:Sx, :Lx].contiguous()
+                dbx = db.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
+                ixx = idx.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
+                ms = time_launches(lambda: eng.batch_device(px, nx, hx, re, db=dbx, index=ixx, stream=cur), cur, reps)
+                bpc = 4 * hx + 5 * R
+                cfgs[name] = {"columns_per_s": Sx * Cx / (ms * 1e-3), "columns_per_launch": Sx * Cx, "kernel_ms": ms,
+                              "fused_kernel": eng.fused(nx, hx, re), "roofline": roofline(Sx * Cx, bpc, ms)}
+                if FLOPS_PER_COLUMN.get(nx):
+                    cfgs[name]["flop_frac"] = FLOPS_PER_COLUMN[nx] * Sx * Cx / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS
+                return cfgs[name]
+
+            measure("configs[0] shape: 1 stream, FFT 1024, hop 256, reassignment OFF", 1, 1 << 20, 1024, 256, False, 50)
+            one = measure("configs[1]: 1 stream, FFT 4096, hop 256, reassignment ON", 1, L, 4096, 256, True, 50)
+            c4 = measure("configs[4]: 64 streams, FFT 16384, hop 512, reassignment ON", 64, L, 16384, 512, True, 3)
+            p4, f4 = profile_for("n16384")
+            if p4:
+                c4["roofline"]["traffic"] = p4.get("hbm_bytes_per_launch") if f4 else None
+                c4["roofline"]["traffic_source"] = f"{p4['file']}{'' if f4 else ' (STALE: kernels changed since, withheld)'}"
+            measure("64 streams, FFT 4096, hop 256, reassignment OFF", 64, L, 4096, 256, False, 3)
+            measure("64 streams, FFT 1024, hop 256, reassignment ON", 64, 1 << 20, 1024, 256, True, 5)
+            line["configs"] = cfgs
+            line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
+
             # the per-bin parity dump (power, column, row for every bin: what the exact-index criterion forces
             # to exist in HBM, BASELINE.md "parity mode") timed on 16 of the streams, as a second roofline point
             import ctypes as C_
@@ -317,31 +483,27 @@ def main():
             rw_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
 
             def dump():
-                rc = lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(),
-                                                   cl_.data_ptr(), rw_.data_ptr(), C_.c_void_p(cur.cuda_stream))
-                assert rc == 0
-            dump()
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            for _ in range(5):
-                dump()
-            e1.record(cur)
-            torch.cuda.synchronize(dev)
-            dms = e0.elapsed_time(e1) / 5
+                rcode = lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(),
+                                                      cl_.data_ptr(), rw_.data_ptr(), C_.c_void_p(cur.cuda_stream))
+                assert rcode == 0
+            dms = time_launches(dump, cur, 5)
             bpc = 4 * hop + 12 * K
-            line["roofline_parity_dump"] = {
-                "bound": "hbm", "achieved": Sd * Cd * bpc / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": Sd * Cd * bpc / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_column": bpc,
-                "columns_per_s": Sd * Cd / (dms * 1e-3), "kernel": "frames_kernel<12> (emspec_parity_dump_device)",
-                "note": "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples"}
+            pd = roofline(Sd * Cd, bpc, dms, "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples")
+            pd["columns_per_s"] = Sd * Cd / (dms * 1e-3)
+            pd["kernel"] = "parity dump (emspec_parity_dump_device)"
+            pp, pf = profile_for("paritydump")
+            pd["traffic"] = pp.get("hbm_bytes_per_launch") if (pp and pf) else None
+            if pp:
+                pd["traffic_source"] = f"{pp['file']}{'' if pf else ' (STALE, withheld)'}"
+            line["roofline_parity_dump"] = pd
             del pw_, cl_, rw_
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n, hop)
             line["cpu_baseline_js"] = js_baseline(n, hop)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,3 +34,12 @@ def gather_columns(local, dst=0, group=None):
 def gather_columns_into(local, out_list, dst=0, group=None):
     """Same, into preallocated per-rank buffers (out_list on dst, None elsewhere): no allocation in the timed path."""
     dist.gather(local, out_list if dist.get_rank(group) == dst else None, dst=dst, group=group)
+
+
+def comm_setup(engine, rank, world, group=None):
+    """Create libemspec's own RCCL communicator on `engine` (emspec_comm_init): rank 0 draws the 128-byte id and
+    torch.distributed carries it to the other ranks - the data path itself never goes through torch."""
+    import emspec
+    box = [emspec.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], rank, world)

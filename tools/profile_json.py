@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_workload.sh run (gpurun_out/<dir>) into the tracked summary bench.py quotes:
+   profiles/<tag>_<workload>.json  +  profiles/<tag>_<workload>_kernel_stats.csv
+usage: tools/profile_json.py gpurun_out/<dir> <tag> <workload> <columns_per_launch>
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: separate --pmc passes, counters in KiB, FETCH_SIZE x 2 on
+gfx950.  The clock is GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same dispatch (guide: within 3 % of the in-kernel
+clock for dispatches >= 10 ms)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag, workload, cols = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+
+
+def rows_of(d):
+    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    return [r for r in csv.DictReader(open(f[0]))] if f else []
+
+
+# the dominant kernel = the emspec kernel with the most total time in the trace
+ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = [r for r in csv.DictReader(open(ks)) if "emspec" in r["Name"]]
+top = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+kname = top["Name"].split("(")[0]
+with open(os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"), "w") as f:
+    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"])):
+        w.writerow(r)
+out = {"workload": workload, "kernel": kname, "columns_per_launch": cols,
+       "sources_sha": open(os.path.join(src, "sources_sha.txt")).read().strip(),
+       "rocprof_avg_ms": float(top["AverageNs"]) * 1e-6, "rocprof_calls": int(top["Calls"]),
+       "command": f"tools/profile_workload.sh {tag}_{workload} (rocprofv3 --kernel-trace --stats; separate --pmc passes)"}
+
+
+def counter(d, name):
+    rows = [r for r in rows_of(d) if r["Counter_Name"] == name and r["Kernel_Name"].startswith(kname)]
+    if not rows:
+        return None, None
+    big = max(int(r["Grid_Size"]) for r in rows)
+    v = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == big]
+    return sum(v) / len(v), rows
+
+
+fetch, _ = counter("pmc_fetch", "FETCH_SIZE")
+write, _ = counter("pmc_write", "WRITE_SIZE")
+if fetch is not None and write is not None:
+    out["read_bytes_per_launch"] = 2.0 * fetch * 1024
+    out["write_bytes_per_launch"] = write * 1024
+    out["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024
+    out["hbm_bytes_per_column"] = out["hbm_bytes_per_launch"] / cols
+    out["hbm_correction"] = "FETCH_SIZE x2 (gfx950), counters in KiB; separate --pmc passes (MI355X_MICROARCH.md §HBM)"
+sq = {}
+for d in ("pmc_sq1", "pmc_sq2"):
+    for r in rows_of(d):
+        if r["Kernel_Name"].startswith(kname):
+            sq.setdefault(r["Counter_Name"], []).append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+sq = {k: sum(x for g, x in v if g == max(g for g, _ in v)) / sum(1 for g, _ in v if g == max(g for g, _ in v)) for k, v in sq.items()}
+if sq:
+    out["sq"] = sq
+    wc = sq.get("SQ_WAVE_CYCLES")
+    if "SQ_INSTS_VALU" in sq:
+        out["valu_insts_per_column"] = sq["SQ_INSTS_VALU"] / cols
+        out["lds_insts_per_column"] = sq.get("SQ_INSTS_LDS", 0) / cols
+    if wc:
+        out["wait_any_share"] = sq.get("SQ_WAIT_ANY", 0) / wc
+        out["active_inst_share"] = sq.get("SQ_ACTIVE_INST_ANY", 0) / wc
+    if sq.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_share"] = sq.get("SQ_LDS_BANK_CONFLICT", 0) / sq["SQ_LDS_IDX_ACTIVE"]
+# clock: GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / duration of that dispatch
+clk_rows = [r for r in rows_of("pmc_clk") if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Kernel_Name"].startswith(kname)]
+kt = glob.glob(os.path.join(src, "pmc_clk", "*", "*_kernel_trace.csv"))
+if clk_rows and kt:
+    dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[0]))}
+    big = max(int(r["Grid_Size"]) for r in clk_rows)
+    ghz = [float(r["Counter_Value"]) / 8.0 / dur[r["Dispatch_Id"]] for r in clk_rows if int(r["Grid_Size"]) == big and r["Dispatch_Id"] in dur]
+    if ghz:
+        out["clock_ghz"] = sum(ghz) / len(ghz)
+        out["clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration (rocprofv3 --pmc GRBM_GUI_ACTIVE, same launch shape)"
+if out.get("valu_insts_per_column") and out.get("clock_ghz"):
+    rate = out["valu_insts_per_column"] * cols / (out["rocprof_avg_ms"] * 1e-3)
+    out["valu_util_at_profile"] = rate * 2.0 / (1024 * out["clock_ghz"] * 1e9)
+json.dump(out, open(os.path.join(dst, f"{tag}_{workload}.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "sq"}, indent=1))

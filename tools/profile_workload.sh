@@ -9,6 +9,7 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.sources_sha())" > "$out/sources_sha.txt" || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --no-cpu-baseline --steps 5 "$@" > "$out/trace.log" 2>&1 || exit 2
 for c in FETCH_SIZE WRITE_SIZE; do
