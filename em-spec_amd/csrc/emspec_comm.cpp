@@ -235,4 +235,35 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     return EMSPEC_OK;
 }
 
+int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                        int32_t root, uint8_t* gathered_index, float* db_local, int64_t* wire_bytes_sent) {
+    if (!e || !pcm) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    emspec_comm_state* c = e->comm;
+    if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first");
+    if (root < 0 || root >= c->world) return fail(e, EMSPEC_ERR_INVALID_ARG, "root out of range");
+    if (c->rank == root && !gathered_index) return fail(e, EMSPEC_ERR_INVALID_ARG, "the root needs the gathered buffer");
+    const int64_t C = emspec_num_columns(L, n, hop);
+    if (S < 1 || C < 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t cells = (size_t)S * (size_t)C * (size_t)e->cfg.rows;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const bool is_root = c->rank == root;
+    const size_t need = al((size_t)S * L * 4) + al(cells) + (db_local ? al(cells * 4) : 0) + (is_root ? al(cells * c->world) : 0) + 256;
+    int rc;
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, need))) return rc;
+    char* base = e->d_stage;
+    float* d_pcm = (float*)base; base += al((size_t)S * L * 4);
+    uint8_t* d_idx = (uint8_t*)base; base += al(cells);
+    float* d_db = nullptr;
+    if (db_local) { d_db = (float*)base; base += al(cells * 4); }
+    uint8_t* d_all = is_root ? (uint8_t*)base : nullptr;
+    HIPCHK(e, hipMemcpyAsync(d_pcm, pcm, (size_t)S * L * 4, hipMemcpyHostToDevice, e->stream));
+    if ((rc = emspec_batch_device(e, d_pcm, S, L, n, hop, reassign, d_db, nullptr, d_idx, e->stream))) return rc;
+    if ((rc = emspec_gather_columns(e, d_idx, (int64_t)S * C, root, d_all, 0, e->stream, wire_bytes_sent))) return rc;
+    if (db_local) HIPCHK(e, hipMemcpyAsync(db_local, d_db, cells * 4, hipMemcpyDeviceToHost, e->stream));
+    if (is_root) HIPCHK(e, hipMemcpyAsync(gathered_index, d_all, cells * c->world, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
 }  // extern "C"

@@ -31,7 +31,7 @@ SYMBOLS = [
     "emspec_get_row_edges_hz", "emspec_host_alloc", "emspec_host_free", "emspec_set_display",
     "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
     "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
-    "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack",
+    "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
 ]
 
 
@@ -105,6 +105,8 @@ def load(diag=False):
     lib.emspec_comm_world.argtypes = [C.c_void_p]
     lib.emspec_gather_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p,
                                           C.POINTER(C.c_int64)]
+    lib.emspec_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.emspec_wire_bound.restype = C.c_int64
     lib.emspec_wire_bound.argtypes = [C.c_int64, C.c_int32]
     lib.emspec_wire_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
@@ -327,6 +329,18 @@ class Engine:
                                                   C.c_void_p(out.data_ptr()) if out is not None else None,
                                                   GATHER_LOOPBACK if loopback else 0, C.c_void_p(st.cuda_stream), C.byref(sent)))
         return int(sent.value)
+
+    def batch_gather(self, pcm, n, hop, reassign=True, root=0, want_db=False):
+        """Host buffers: this rank's streams -> (gathered index [world,S,C,rows] on root else None, own dB or None, wire bytes)."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        S, L = pcm.shape
+        Cn = num_columns(L, n, hop)
+        allidx = np.empty((self.comm_world, S, Cn, self.rows), np.uint8) if self.comm_rank == root else None
+        db = np.empty((S, Cn, self.rows), np.float32) if want_db else None
+        sent = C.c_int64(0)
+        self._chk(self._lib.emspec_batch_gather(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), root, _np_ptr(allidx),
+                                                _np_ptr(db), C.byref(sent)))
+        return allidx, db, int(sent.value)
 
     def wire_pack(self, index_t, wire_t, stream=None, want_size=True):
         """index_t uint8 CUDA [columns, rows] -> wire_t (uint8 CUDA, >= wire_bound bytes); returns the image size."""

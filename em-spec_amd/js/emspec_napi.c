@@ -34,6 +34,7 @@ static const char* status_name(int rc) {
         case EMSPEC_ERR_HIP: return "EMSPEC_ERR_HIP";
         case EMSPEC_ERR_OUT_OF_MEMORY: return "EMSPEC_ERR_OUT_OF_MEMORY";
         case EMSPEC_ERR_STATE: return "EMSPEC_ERR_STATE";
+        case EMSPEC_ERR_COMM: return "EMSPEC_ERR_COMM";
         default: return "EMSPEC_ERR_UNKNOWN";
     }
 }
@@ -43,7 +44,7 @@ static napi_value throw_status(napi_env env, emspec_engine* e, int rc) {
     return NULL;
 }
 
-typedef struct { emspec_engine* e; } handle_t;
+typedef struct { emspec_engine* e; int32_t rows; } handle_t;   /* rows: the engine's row count, for output-size checks */
 
 static void finalize_handle(napi_env env, void* data, void* hint) {
     (void)env; (void)hint;
@@ -112,6 +113,7 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     handle_t* h = (handle_t*)malloc(sizeof(handle_t));
     if (!h) { emspec_destroy(e); napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
     h->e = e;
+    h->rows = cfg.rows;
     napi_value ext;
     if (napi_create_external(env, h, finalize_handle, NULL, &ext) != napi_ok) {
         finalize_handle(env, h, NULL);
@@ -300,8 +302,9 @@ static napi_value Batch(napi_env env, napi_callback_info info) {
     /* sizes are checked against rows implied by the first output given */
     size_t cells = 0;
     if (p0) cells = l0; else if (p1) cells = l1 / 4; else if (p2) cells = l2;
-    if (C <= 0 || cells == 0 || cells % ((size_t)S * (size_t)C) != 0 || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
-        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold S*columns*rows cells (rgba: 4 bytes per cell)");
+    /* emspec_batch writes S*columns*rows cells with the ENGINE's row count: anything else would overrun the array */
+    if (C <= 0 || cells != (size_t)S * (size_t)C * (size_t)h->rows || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold exactly S*columns*rows cells, rows = the engine's row count (rgba: 4 bytes per cell)");
         return NULL;
     }
     out.db = (float*)p0; out.rgba = (uint8_t*)p1; out.index = (uint8_t*)p2;
@@ -374,8 +377,8 @@ static napi_value BatchAsync(napi_env env, napi_callback_info info) {
     if (argc > 9 && !get_typed(env, argv[9], napi_uint8_array, &p2, &l2, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outIndex must be a Uint8Array"); return NULL; }
     int64_t C = emspec_num_columns(L, n, hop);
     size_t cells = p0 ? l0 : (p1 ? l1 / 4 : l2);
-    if (C <= 0 || cells == 0 || cells % ((size_t)S * (size_t)C) != 0 || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
-        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold S*columns*rows cells (rgba: 4 bytes per cell)");
+    if (C <= 0 || cells != (size_t)S * (size_t)C * (size_t)h->rows || (p1 && l1 != 4 * cells) || (p2 && l2 != cells) || (p0 && l0 != cells)) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "output arrays must hold exactly S*columns*rows cells, rows = the engine's row count (rgba: 4 bytes per cell)");
         return NULL;
     }
     batch_job* j = (batch_job*)calloc(1, sizeof(batch_job));
@@ -487,6 +490,67 @@ static napi_value LatencyColumns(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* ---- multi-GPU (include/emspec.h "Multi-GPU"): one node process per GPU ---- */
+/* commUniqueId() -> Uint8Array(128): rank 0 calls it and hands the bytes to the other rank processes (IPC, a file...) */
+static napi_value CommUniqueId(napi_env env, napi_callback_info info) {
+    (void)info;
+    void* data; napi_value ab, ta;
+    NAPI_OK_OR_RETURN(env, napi_create_arraybuffer(env, EMSPEC_COMM_ID_BYTES, &data, &ab));
+    if (emspec_comm_unique_id((uint8_t*)data) != EMSPEC_OK) { napi_throw_error(env, "EMSPEC_ERR_COMM", emspec_last_error(NULL)); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_create_typedarray(env, napi_uint8_array, EMSPEC_COMM_ID_BYTES, ab, 0, &ta));
+    return ta;
+}
+/* commInit(handle, id:Uint8Array(128), rank, world): collective over all rank processes */
+static napi_value CommInit(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 4) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "commInit(handle, id, rank, world)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* id; size_t len; int32_t rank, world;
+    if (!get_typed(env, argv[1], napi_uint8_array, &id, &len, 0) || len != EMSPEC_COMM_ID_BYTES) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "id must be the Uint8Array(128) of commUniqueId()"); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &rank));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &world));
+    int rc = emspec_comm_init(h->e, (const uint8_t*)id, rank, world);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+/* batchGather(handle, pcm, S, L, fftSize, hop, reassign, root, outAllIndex?:Uint8Array(world*S*C*rows), outDb?:Float32Array(S*C*rows))
+ * -> bytes this rank put on the wire.  Collective: every rank process calls it with its own shard of the streams. */
+static napi_value BatchGather(napi_env env, napi_callback_info info) {
+    size_t argc = 10; napi_value argv[10];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 8) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "batchGather(handle, pcm, S, L, fftSize, hop, reassign, root[, outAllIndex, outDb])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* pcm; size_t plen;
+    if (!get_typed(env, argv[1], napi_float32_array, &pcm, &plen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm must be a Float32Array"); return NULL; }
+    int32_t S, n, hop, root; int64_t L; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[3], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[6], &argv[6]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[6], &reassign));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[7], &root));
+    if (S < 1 || L < 1 || (size_t)S * (size_t)L != plen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm.length must equal S*L"); return NULL; }
+    void *pall = NULL, *pdb = NULL; size_t lall = 0, ldb = 0;
+    if (argc > 8 && !get_typed(env, argv[8], napi_uint8_array, &pall, &lall, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outAllIndex must be a Uint8Array"); return NULL; }
+    if (argc > 9 && !get_typed(env, argv[9], napi_float32_array, &pdb, &ldb, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    const int64_t C = emspec_num_columns(L, n, hop);
+    const int32_t world = emspec_comm_world(h->e), rank = emspec_comm_rank(h->e);
+    const size_t cells = (size_t)S * (size_t)(C > 0 ? C : 0) * (size_t)h->rows;
+    if (world < 1) { napi_throw_error(env, "EMSPEC_ERR_STATE", "no communicator: call commInit first"); return NULL; }
+    if (C <= 0 || (rank == root && lall != cells * (size_t)world) || (pdb && ldb != cells)) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outAllIndex must hold world*S*columns*rows bytes on the root, outDb S*columns*rows floats");
+        return NULL;
+    }
+    int64_t sent = 0;
+    int rc = emspec_batch_gather(h->e, (const float*)pcm, S, L, n, hop, reassign ? 1 : 0, root, rank == root ? (uint8_t*)pall : NULL,
+                                 (float*)pdb, &sent);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, sent, &r));
+    return r;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     napi_property_descriptor props[] = {
         {"create", NULL, Create, NULL, NULL, NULL, napi_default, NULL},
@@ -508,6 +572,9 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"allocPinned", NULL, AllocPinned, NULL, NULL, NULL, napi_default, NULL},
         {"numColumns", NULL, NumColumns, NULL, NULL, NULL, napi_default, NULL},
         {"latencyColumns", NULL, LatencyColumns, NULL, NULL, NULL, napi_default, NULL},
+        {"commUniqueId", NULL, CommUniqueId, NULL, NULL, NULL, napi_default, NULL},
+        {"commInit", NULL, CommInit, NULL, NULL, NULL, napi_default, NULL},
+        {"batchGather", NULL, BatchGather, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
     return exports;

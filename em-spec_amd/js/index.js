@@ -70,6 +70,17 @@ class Engine {
     return native.batchAsync(this._h, pcm, S, L, fftSize, hop, !!reassign, out.db, out.rgba, out.index);
   }
 
+  /** Multi-GPU (one node process per GPU): join the gather communicator.  id = commUniqueId() of rank 0, handed over by
+   *  the host's own channel (IPC, a file); collective over all `world` rank processes. */
+  commInit(id, rank, world) { native.commInit(this._h, id, rank, world); this.commRank = rank; this.commWorld = world; }
+
+  /** This rank's shard of the streams -> finished columns, gathered on `root` over RCCL (packed on the wire).
+   *  out.allIndex (root): Uint8Array(world*S*C*rows), rank-major; out.db (optional): this rank's own dB columns.
+   *  Returns the bytes this rank put on the wire.  Collective: every rank process calls it. */
+  computeColumnsGather(pcm, S, L, fftSize, hop, reassign, root, out) {
+    return native.batchGather(this._h, pcm, S, L, fftSize, hop, !!reassign, root, out.allIndex, out.db);
+  }
+
   setColormap(rgba256) { native.setColormap(this._h, rgba256); }
 
   /** Temporal smoothing (0..0.95) and adaptive brightness / AGC strength (0..1); 0,0 = off. */
@@ -140,6 +151,7 @@ module.exports = {
   warpedEdges,
   makeColormap,
   colormapStops,
+  commUniqueId: native.commUniqueId,
   numColumns: native.numColumns,
   latencyColumns: native.latencyColumns,
 };

@@ -2,7 +2,66 @@
 /* Node smoke test of the drop-in call on a GPU box: BASELINE config 1 (FFT 1024, hop 256,
  * reassignment off) frame by frame, and config 2 shape (4096/256, reassignment on) against
  * the batched entry point.  Exits non-zero on any mismatch.  Run: node test_emspec.js */
+const path = require('path');
 const em = require('./index.js');
+// the plain-JS float64 restatement (TEST INFRASTRUCTURE: oracle/js/reassign_ref.js) - the checker, never the product
+const ref = require(path.join(__dirname, '..', '..', 'oracle', 'js', 'reassign_ref.js'));
+
+/* The addon against the plain-JS float64 three-window method (an implementation that shares nothing with the HIP
+ * kernels): streaming computeSpectrogramColumn + flush, and the batched call.  float32 and float64 disagree on a bin
+ * that sits on a cell edge and cells near the display floor carry float32 rounding noise, so the bound is statistical:
+ * of the cells the float64 method puts above -60 dB, >= 99 % within 0.01 dB, median error < 1e-4 dB. */
+function checkAgainstJsOracle(fftSize, hop, reassign, frames) {
+  const eng = em.createEngine({});
+  const L = fftSize + hop * (frames - 1);
+  const pcm = synth(L);
+  const R = eng.rows;
+  const want = ref.columnsDb(pcm, fftSize, hop, reassign, frames);
+  const D = em.latencyColumns(fftSize, hop, reassign);
+  const got = new Float32Array(frames * R);
+  for (let j = 0; j < frames; j++) {
+    const col = eng.computeSpectrogramColumn(pcm.subarray(j * hop, j * hop + fftSize), fftSize, hop, reassign);
+    if (eng.lastColumn >= 0) got.set(col, eng.lastColumn * R);
+  }
+  for (let k = 0; k < Math.min(D, frames); k++) { const col = eng.flush(); got.set(col, eng.lastColumn * R); }
+  const batch = new Float32Array(frames * R);
+  eng.computeColumns(pcm, 1, L, fftSize, hop, reassign, { db: batch });
+  for (const [name, arr] of [['streaming', got], ['batch', batch]]) {
+    const errs = [];
+    for (let i = 0; i < want.length; i++) if (want[i] > -60) errs.push(Math.abs(arr[i] - want[i]));
+    errs.sort((a, b) => a - b);
+    const within = errs.filter((e) => e < 1e-2).length / errs.length, med = errs[errs.length >> 1];
+    if (!(errs.length > 100 && within > 0.99 && med < 1e-4))
+      throw new Error(name + ' vs plain-JS float64 oracle: ' + errs.length + ' strong cells, ' + within + ' within 0.01 dB, median ' + med);
+  }
+  eng.destroy();
+}
+
+/* multi-GPU entry points on one rank: communicator creation, batch + RCCL gather (world 1: the root's own columns) */
+function checkGatherOneRank() {
+  const eng = em.createEngine({});
+  const fftSize = 4096, hop = 256, frames = 40, S = 2, L = fftSize + hop * (frames - 1);
+  const pcm = new Float32Array(S * L);
+  pcm.set(synth(L), 0); pcm.set(synth(L).map((v, i) => v * (i % 7 ? 1 : 0.5)), L);
+  const R = eng.rows;
+  const idx = new Uint8Array(S * frames * R), all = new Uint8Array(S * frames * R), db = new Float32Array(S * frames * R);
+  eng.computeColumns(pcm, S, L, fftSize, hop, true, { index: idx });
+  let threw = false;
+  try { eng.computeColumnsGather(pcm, S, L, fftSize, hop, true, 0, { allIndex: all }); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
+  if (!threw) throw new Error('gather without a communicator must throw EMSPEC_ERR_STATE');
+  const id = em.commUniqueId();
+  if (!(id instanceof Uint8Array) || id.length !== 128) throw new Error('commUniqueId');
+  eng.commInit(id, 0, 1);
+  eng.computeColumnsGather(pcm, S, L, fftSize, hop, true, 0, { allIndex: all, db });
+  for (let i = 0; i < idx.length; i++) if (idx[i] !== all[i]) throw new Error('gathered index differs from the batch index at ' + i);
+  threw = false;
+  try { eng.computeColumnsGather(pcm, S, L, fftSize, hop, true, 0, { allIndex: new Uint8Array(10) }); } catch (e) { threw = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!threw) throw new Error('short gather buffer must throw EMSPEC_ERR_INVALID_ARG');
+  threw = false;   // ADVICE r01: an output sized for fewer rows than the engine's must be refused, not overrun
+  try { eng.computeColumns(pcm, S, L, fftSize, hop, true, { db: new Float32Array(S * frames * 512) }); } catch (e) { threw = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!threw) throw new Error('batch output with the wrong row count must throw EMSPEC_ERR_INVALID_ARG');
+  eng.destroy();
+}
 
 function synth(L) {
   const x = new Float32Array(L);
@@ -113,6 +172,9 @@ async function checkAsync() {
   eng.destroy();
 }
 
+checkAgainstJsOracle(1024, 256, false, 40);
+checkAgainstJsOracle(4096, 256, true, 48);
+checkGatherOneRank();
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);
 checkPush(4096, 256, true, 150);

@@ -278,6 +278,16 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
                           uint8_t* gathered_dev, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent);
 
 /*
+ * Host-buffer convenience for a rank process (the N-API addon's computeColumnsGather): this rank's S streams
+ * (pcm[S][L], host memory) -> finished columns on the device -> emspec_gather_columns -> on `root` the palette-index
+ * columns of all ranks in host memory, gathered_index[world][S][columns][rows] (ignored elsewhere).  db_local
+ * (optional, any rank): this rank's own float32 dB columns [S][columns][rows].  Synchronous; collective.
+ */
+int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                        int32_t reassign, int32_t root, uint8_t* gathered_index, float* db_local,
+                        int64_t* wire_bytes_sent);
+
+/*
  * The wire image by itself, for hosts that bring their own transport: header (32 B) + ceil(rows/32) mask words
  * per column + the non-zero indices (column-major, rows ascending), see em-spec_amd/csrc/pack.hip.inc.
  * emspec_wire_bound: capacity a destination needs for `columns` columns (-1 on invalid arguments).

@@ -138,7 +138,27 @@ function bench(argv) {
   console.log(JSON.stringify({ columns_per_s: cols / dt, columns: cols, seconds: dt, n, hop, node: process.version }));
 }
 
-const mode = process.argv[2];
-if (mode === 'check') check(process.argv.slice(3));
-else if (mode === 'bench') bench(process.argv.slice(3));
-else { console.error('usage: node reassign_ref.js check|bench ...'); process.exit(2); }
+/* finished dB columns of one stream, float64 throughout (histogram scatter, 10 log10): what a plain-JS renderer
+ * would draw.  Returns Float64Array(frames * rows). */
+function columnsDb(pcm, n, hop, reassign, frames, opts) {
+  const plan = makePlan(n, hop, Object.assign({ reassign: !!reassign }, opts || {}));
+  const K = plan.K, R = plan.o.rows;
+  const out = { power: new Float64Array(K), that: new Float64Array(K), khat: new Float64Array(K), col: new Int32Array(K), row: new Int32Array(K) };
+  const hist = new Float64Array(frames * R), db = new Float64Array(frames * R);
+  for (let j = 0; j < frames; j++) {
+    frame(plan, pcm, j, out, 0);
+    for (let k = 0; k < K; k++) { const c = out.col[k], r = out.row[k]; if (r >= 0 && c >= 0 && c < frames) hist[c * R + r] += out.power[k]; }
+  }
+  const scale = 32 / (3 * n * n);
+  for (let i = 0; i < hist.length; i++) db[i] = 10 * Math.log10(hist[i] * scale + 1e-20);
+  return db;
+}
+
+if (require.main === module) {
+  const mode = process.argv[2];
+  if (mode === 'check') check(process.argv.slice(3));
+  else if (mode === 'bench') bench(process.argv.slice(3));
+  else { console.error('usage: node reassign_ref.js check|bench ...'); process.exit(2); }
+} else {
+  module.exports = { makePlan, frame, columnsDb };
+}
