@@ -89,7 +89,9 @@ __device__ __forceinline__ void fft_stages(float2 (&v)[1 << R], int lo, const fl
 
 // The same stages with the twiddle of slot e supplied by w(e); slots are numbered stage by
 // stage: slot = 2^R - 2*mloc + (i mod mloc), mloc = 2^(R-1-u) for local stage u.
-template <int R, class W>
+// LEAN: a scheduling barrier after the first stage keeps the later stages' twiddle reads from being hoisted above
+// it (with 16 points that is 14 fewer live registers at the pass's peak; fused_n16384.hip.inc needs them).
+template <int R, class W, bool LEAN = false>
 __device__ __forceinline__ void fft_stages_w(float2 (&v)[1 << R], const W& w) {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -101,6 +103,7 @@ __device__ __forceinline__ void fft_stages_w(float2 (&v)[1 << R], const W& w) {
             v[i] = cadd(a, b);
             v[i + mloc] = cmul_tw(csub(a, b), w((1 << R) - 2 * mloc + (i & (mloc - 1))));
         }
+        if constexpr (LEAN) { if (u == 0) __builtin_amdgcn_sched_barrier(0); }
     }
 }
 // twiddle-table index of slot e (radix-16 pass starting at stage S0) for low index lo

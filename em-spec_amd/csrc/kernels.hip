@@ -99,7 +99,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
         float2 v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = sm[padi(base + (i << B0))];
-        fft_stages_w<4>(v, TwLdsStrided{stw + lo, 1 << B0});
+        fft_stages_w<4, TwLdsStrided, PRIO>(v, TwLdsStrided{stw + lo, 1 << B0});   // PRIO builds (fused N = 16384) are also the register-lean ones
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm[padi(base + (i << B0))] = v[i];
         wave_lds_sync();

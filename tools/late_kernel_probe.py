@@ -13,8 +13,8 @@ from bench import synth_device
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 S, L, n, hop = 64, 1 << 22, 4096, 256
-eng = emspec.Engine(device=0)
-lib = emspec.load()
+eng = emspec.Engine(device=0, diag=True)
+lib = emspec.load(diag=True)
 lib.emspec_debug_occupy.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
 R, Cn = eng.rows, emspec.num_columns(L, n, hop)
 pcm = synth_device(S, L, 0, dev)

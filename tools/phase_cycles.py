@@ -15,8 +15,8 @@ from bench import synth_device
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 L = 1 << 22
 n, hop = 4096, 256
-eng = emspec.Engine()
-lib = emspec.load()
+eng = emspec.Engine(diag=True)      # the stamped build lives in libemspec_diag.so
+lib = emspec.load(diag=True)
 dev = torch.device("cuda", 0)
 pcm = synth_device(S, L, 0, dev)
 Cn = emspec.num_columns(L, n, hop)
@@ -32,13 +32,13 @@ torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
 names = ["passA+write", "barrier wait", "finalize+passB", "passC r/c", "passD in place", "bins+scatter+A", "loop tail", "-"]
-tot = cyc.sum(axis=2).astype(np.float64)
+tot = cyc[:, :, :7].sum(axis=2).astype(np.float64)    # slot 7 is not a phase: rounds (low word) + 100 MHz ticks (high word)
 print(f"groups {groups.value}; mean cycles per wave {tot.mean():.0f} (readcyclecounter units)")
 for i, nm in enumerate(names[:7]):
     v = cyc[:, :, i].astype(np.float64)
     print(f"  {nm:16s} {100 * v.sum() / tot.sum():5.1f} %   per-iteration {v.mean() / ((Cn / (groups.value / S) + 16) / 2):8.0f}")
 it_ = (Cn / (groups.value / S) + 16) / 2
-print(f"accumulate rounds per wave per frame (4 calls): {cyc[:, :, 7].astype(np.float64).mean() / it_:.2f}")
+print(f"accumulate rounds per wave per frame (4 calls): {(cyc[:, :, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64).mean() / it_:.2f}")
 if len(sys.argv) > 2:
     print("per-wave mean cycles per iteration (rows: wave, cols: phases)")
     it = (Cn / (groups.value / S) + 16) / 2

@@ -17,13 +17,22 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 
 
+def newest(pattern):
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
 def rows_of(d):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
-    return [r for r in csv.DictReader(open(f[0]))] if f else []
+    f = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    return [r for r in csv.DictReader(open(f))] if f else []
+
+
+def grid(r):
+    return int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
 
 
 # the dominant kernel = the emspec kernel with the most total time in the trace
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+ks = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 stats = [r for r in csv.DictReader(open(ks)) if "emspec" in r["Name"]]
 top = max(stats, key=lambda r: float(r["TotalDurationNs"]))
 kname = top["Name"].split("(")[0]
@@ -32,9 +41,19 @@ with open(os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"), "w") as f:
     w.writeheader()
     for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"])):
         w.writerow(r)
+# per-launch durations of that kernel from the same pass's kernel trace, timed launches only (= the largest grid: the
+# default bench command also launches the kernel on one stream for its `configs` side measurements)
+kt0 = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+durs = []
+if kt0:
+    rows0 = [r for r in csv.DictReader(open(kt0)) if r["Kernel_Name"].startswith(kname)]
+    big0 = max(grid(r) for r in rows0)
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rows0 if grid(r) == big0]
 out = {"workload": workload, "kernel": kname, "columns_per_launch": cols,
        "sources_sha": open(os.path.join(src, "sources_sha.txt")).read().strip(),
-       "rocprof_avg_ms": float(top["AverageNs"]) * 1e-6, "rocprof_calls": int(top["Calls"]),
+       "rocprof_avg_ms": (sum(durs) / len(durs)) if durs else float(top["AverageNs"]) * 1e-6,
+       "rocprof_calls": len(durs) if durs else int(top["Calls"]),
+       "rocprof_stats_avg_ms_all_launches": float(top["AverageNs"]) * 1e-6,
        "command": f"tools/profile_workload.sh {tag}_{workload} (rocprofv3 --kernel-trace --stats; separate --pmc passes)"}
 
 
@@ -74,9 +93,9 @@ if sq:
         out["lds_bank_conflict_share"] = sq.get("SQ_LDS_BANK_CONFLICT", 0) / sq["SQ_LDS_IDX_ACTIVE"]
 # clock: GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / duration of that dispatch
 clk_rows = [r for r in rows_of("pmc_clk") if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Kernel_Name"].startswith(kname)]
-kt = glob.glob(os.path.join(src, "pmc_clk", "*", "*_kernel_trace.csv"))
+kt = newest(os.path.join(src, "pmc_clk", "*", "*_kernel_trace.csv"))
 if clk_rows and kt:
-    dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt[0]))}
+    dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(kt))}
     big = max(int(r["Grid_Size"]) for r in clk_rows)
     ghz = [float(r["Counter_Value"]) / 8.0 / dur[r["Dispatch_Id"]] for r in clk_rows if int(r["Grid_Size"]) == big and r["Dispatch_Id"] in dur]
     if ghz:
