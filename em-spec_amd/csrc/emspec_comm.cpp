@@ -9,7 +9,7 @@
 // One process (or thread) per GPU, one engine per process; the streams are sharded by the host, every rank runs
 // emspec_batch_device on its own shard, and the only exchange is this gather.  xGMI is point-to-point, so each
 // rank reaches the root over one link: the columns travel in the lossless wire image of pack.hip.inc
-// (bit mask + non-zero indices, ~190 B instead of 1024 B per column on the bench input) and are expanded on the
+// (per-column payload offset + bit mask + non-zero indices, ~186 B instead of 1024 B per column on the bench input) and are expanded on the
 // root.  Sizes differ per rank and RCCL's send/recv counts must match on both sides, so a gather is
 //     pack (GPU)  ->  ncclAllGather of the 8-byte image sizes  ->  one host sync to read them
 //     ->  grouped ncclSend (ranks) / ncclRecv x (world-1) (root)  ->  expand on the root (GPU)
@@ -30,7 +30,8 @@ int64_t wire_bound_bytes(int64_t columns, int rows);
 size_t wire_scratch_bytes(int64_t columns);
 uint64_t* wire_total_ptr(void* scratch, int64_t columns);
 hipError_t launch_wire_pack(const uint8_t* index, int64_t columns, int rows, uint8_t* wire, void* scratch, hipStream_t st);
-hipError_t launch_wire_unpack(const uint8_t* wire, int64_t columns, int rows, uint8_t* index, void* scratch, hipStream_t st);
+hipError_t launch_wire_unpack(const uint8_t* wire, int64_t columns, int rows, uint8_t* index, hipStream_t st);
+int64_t wire_fixed_bytes(int64_t columns, int rows);
 }  // namespace emspec
 
 struct emspec_comm_state {
@@ -157,13 +158,11 @@ int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_b
     HIPCHK(e, hipMemcpyAsync(h, wire_dev, sizeof(h), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
     const uint64_t hcols = (uint64_t)h[2] | ((uint64_t)h[3] << 32), hpay = (uint64_t)h[4] | ((uint64_t)h[5] << 32);
-    const int64_t need = 32 + columns * (int64_t)(((e->cfg.rows + 31) >> 5) * 4) + (int64_t)((hpay + 15) & ~(uint64_t)15);
-    if (h[0] != 0x31574D45u || (int32_t)h[1] != e->cfg.rows || hcols != (uint64_t)columns || hpay > (uint64_t)columns * e->cfg.rows ||
+    const int64_t need = wire_fixed_bytes(columns, e->cfg.rows) + (int64_t)((hpay + 15) & ~(uint64_t)15);
+    if (h[0] != 0x32574D45u /* "EMW2" */ || (int32_t)h[1] != e->cfg.rows || hcols != (uint64_t)columns || hpay > (uint64_t)columns * e->cfg.rows ||
         wire_bytes < need)
         return fail(e, EMSPEC_ERR_INVALID_ARG, "wire image does not match this engine's rows / the column count");
-    int rc;
-    if ((rc = grow(e, &c->d_scratch, &c->scratch_bytes, wire_scratch_bytes(columns)))) return rc;
-    HIPCHK(e, launch_wire_unpack(wire_dev, columns, e->cfg.rows, index_dev, c->d_scratch, st));
+    HIPCHK(e, launch_wire_unpack(wire_dev, columns, e->cfg.rows, index_dev, st));
     return EMSPEC_OK;
 }
 
@@ -229,7 +228,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
                 if (dst != index_dev) HIPCHK(e, hipMemcpyAsync(dst, index_dev, col_bytes, hipMemcpyDeviceToDevice, st));
                 continue;
             }
-            HIPCHK(e, launch_wire_unpack(c->d_recv + off[r], columns, R, dst, c->d_scratch, st));
+            HIPCHK(e, launch_wire_unpack(c->d_recv + off[r], columns, R, dst, st));
         }
     }
     return EMSPEC_OK;

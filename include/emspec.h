@@ -265,7 +265,7 @@ int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator
  * [columns][rows] on its device (columns = streams * columns-per-stream of the shard; the same on every rank).
  * gathered_dev (root only; ignored elsewhere): [world][columns][rows] on the root's device.
  * xGMI is point-to-point - each rank reaches the root over one link - so the columns travel as a lossless packed
- * image (bit mask of the non-zero cells + their indices; emspec_wire_* below) and are expanded on the root.
+ * image (per-column offset + bit mask of the non-zero cells + their indices; emspec_wire_* below) and are expanded on the root.
  * The call enqueues everything on hip_stream and synchronises that stream ONCE (the packed sizes differ per rank
  * and must be known on the host before the transfers can be posted): enqueue the next chunk's
  * emspec_batch_device on another stream BEFORE calling it, and the gather overlaps that compute.
@@ -288,8 +288,9 @@ int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L
                         int64_t* wire_bytes_sent);
 
 /*
- * The wire image by itself, for hosts that bring their own transport: header (32 B) + ceil(rows/32) mask words
- * per column + the non-zero indices (column-major, rows ascending), see em-spec_amd/csrc/pack.hip.inc.
+ * The wire image by itself, for hosts that bring their own transport: header (32 B) + a u32 payload offset per
+ * column + ceil(rows/32) mask words per column + the non-zero indices (column after column, rows ascending), see
+ * em-spec_amd/csrc/pack.hip.inc.
  * emspec_wire_bound: capacity a destination needs for `columns` columns (-1 on invalid arguments).
  * emspec_wire_pack:  index_dev [columns][rows] -> wire_dev; *wire_bytes (optional) = the image size (reading it
  *                    synchronises hip_stream; pass NULL to stay asynchronous).

@@ -25,7 +25,7 @@ def test_wire_ref_round_trip(columns, rows, density):
     w = W.pack(idx)
     assert w.size <= W.bound(columns, rows)
     assert np.array_equal(W.unpack(w, columns, rows), idx)
-    assert w.size == 32 + columns * W.mask_words(rows) * 4 + ((int((idx != 0).sum()) + 15) // 16) * 16
+    assert w.size == W.fixed_bytes(columns, rows) + ((int((idx != 0).sum()) + 15) // 16) * 16
 
 
 def test_wire_bound_matches_ref():
@@ -49,8 +49,8 @@ def test_pack_kernels_match_wire_ref(columns, rows, density):
         nbytes = e.wire_pack(t, wire)
         assert nbytes == ref.size
         got = wire[:nbytes].cpu().numpy()
-        pay_end = 32 + columns * W.mask_words(rows) * 4 + int((idx != 0).sum())
-        assert np.array_equal(got[:pay_end], ref[:pay_end])        # header, masks, payload (the pad bytes are don't-care)
+        pay_end = W.fixed_bytes(columns, rows) + int((idx != 0).sum())
+        assert np.array_equal(got[:pay_end], ref[:pay_end])        # header, offsets, masks, payload (the pad bytes are don't-care)
         back = torch.full_like(t, 0xCD)
         e.wire_unpack(wire, nbytes, back)
         torch.cuda.synchronize()
