@@ -115,6 +115,7 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     d.tscale = (float)((double)p.n / 2.0 / (double)hop);
     const double pk = (double)p.n / 4.0;   // |X_h| of a full-scale sine
     d.pfloor_abs = (float)((double)e->cfg.power_floor * pk * pk);
+    d.shared = comm_shares_device(e) ? 1 : 0;
     return d;
 }
 

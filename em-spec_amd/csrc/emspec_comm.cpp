@@ -70,6 +70,7 @@ emspec_comm_state* state(emspec_engine* e) {
 }  // namespace
 
 namespace emspec {
+bool comm_shares_device(const emspec_engine* e) { return e->comm && e->comm->comm && e->comm->world > 1; }
 void comm_destroy(emspec_engine* e) {
     emspec_comm_state* c = e->comm;
     if (!c) return;

@@ -23,7 +23,24 @@ struct PlanDev {
     int hop;
     float tscale;        // (N/2)/hop : normalised time shift -> columns
     float pfloor_abs;    // gate on |X_h|^2
+    int shared;          // host side only: the device is shared with a collective (engine has a communicator, world > 1)
 };
+
+// How a launch of a fused (walking) kernel cuts every stream into segments: grid = (streams, segments).  Segment g of a
+// stream covers columns [g * seglen, (g + 1) * seglen) for g < nlong, then pieces of `tail` columns.  Workgroups are
+// dispatched in linear block order, so with blockIdx.y = segment all streams' long segments start first and the
+// launch ends on the short ones: when another kernel (a collective, the gather's pack / expand) holds some CUs and the
+// workgroups no longer fill whole rounds, what is left over at the end is short.  nlong >= segments:
+// uniform segments.
+struct SegPlan { int seglen; int nlong; int tail; };
+__device__ __forceinline__ bool seg_of_block(const SegPlan& sp, int64_t C, int& s, int64_t& c0, int64_t& c1) {
+    s = (int)blockIdx.x;
+    const int g = (int)blockIdx.y;
+    const int64_t len = g < sp.nlong ? sp.seglen : sp.tail;
+    c0 = g < sp.nlong ? (int64_t)g * sp.seglen : (int64_t)sp.nlong * sp.seglen + (int64_t)(g - sp.nlong) * sp.tail;
+    c1 = (c0 + len < C) ? c0 + len : C;
+    return c0 < C;
+}
 
 struct DbMap {           // stage "dB + colour"
     float scale;         // 32/(3 N^2) * gain^2 : full-scale sine -> 1.0

@@ -75,6 +75,7 @@ int fail(const emspec_engine* e, int code, const std::string& msg);
 // (re)allocates *ptr to at least `want` bytes of device memory
 int grow(emspec_engine* e, void** ptr, size_t* have, size_t want);
 void comm_destroy(emspec_engine* e);   // emspec_comm.cpp: called by emspec_destroy
+bool comm_shares_device(const emspec_engine* e);   // the engine has a communicator with other ranks (world > 1)
 }  // namespace emspec
 
 #define HIPCHK(e, call)                                                                          \

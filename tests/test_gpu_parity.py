@@ -165,6 +165,27 @@ def test_fused_n16384_short_segments(hop, seglen, frames, monkeypatch):
     assert d.max() <= 1 and np.mean(d != 0) < 1e-3
 
 
+@pytest.mark.parametrize("n,hop,frames,S", [(4096, 256, 2300, 2), (4096, 512, 700, 3), (8192, 512, 900, 2), (2048, 128, 1500, 2),
+                                            (1024, 256, 2000, 2), (16384, 512, 700, 2), (4096, 256, 130, 1)])
+def test_shared_device_segment_plan(n, hop, frames, S, monkeypatch):
+    """When the engine shares its GPU with a collective (communicator, world > 1) a launch cuts the last quarter of every
+    stream into quarter-length segments and dispatches the long ones first (SegPlan, fused.hip.inc).  EMSPEC_SHARED=1
+    (diagnostic build) selects that plan on one GPU: results must not depend on how a stream is cut."""
+    import emspec
+    monkeypatch.setenv("EMSPEC_SHARED", "1")
+    pcm = _pcm(n, hop, frames, S=S)
+    eng = emspec.Engine(diag=True)
+    try:
+        assert eng.fused(n, hop, True)
+        out = eng.batch(pcm, n, hop, True, want=("db", "index"))
+    finally:
+        eng.close()
+    odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
+    d = np.abs(out["index"].astype(int) - oidx.astype(int))
+    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+
+
 def test_generic_records_path_still_serves_n16384_small_hop(engine):
     """N = 16384 at hop 256 needs 65 ring slots: not fused, stays on per-bin records + walk/tile scatter."""
     n, hop, frames = 16384, 256, 80

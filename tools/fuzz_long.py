@@ -13,7 +13,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 SHAPES = [(4096, 256), (4096, 512), (4096, 1024), (4096, 300), (4096, 2048), (8192, 512), (8192, 1024),
-          (2048, 128), (2048, 256), (2048, 200), (2048, 1000), (1024, 128), (1024, 256), (1024, 100), (1024, 700)]
+          (2048, 128), (2048, 256), (2048, 200), (2048, 1000), (1024, 128), (1024, 256), (1024, 100), (1024, 700),
+          (16384, 512), (16384, 512), (16384, 1024), (16384, 700), (16384, 4096)]
 fails, t0 = 0, time.time()
 for ci in range(cases):
     n, hop = SHAPES[int(rng.integers(0, len(SHAPES)))]
@@ -21,6 +22,8 @@ for ci in range(cases):
     rows = int(rng.choice([64, 256, 512, 1024, 1024]))
     S = int(rng.integers(1, 4))
     frames = int(rng.integers(200, 2500))
+    if n == 16384:
+        frames = int(rng.integers(60, 500))            # the CPU oracle takes ~1 ms per frame at this size
     if n * 1 + hop * frames * S > 4e6:
         frames = max(50, int((4e6 / S - n) / hop))
     L = n + hop * (frames - 1) + int(rng.integers(0, hop))
@@ -35,7 +38,7 @@ for ci in range(cases):
         pcm[:, :: int(rng.integers(300, 5000))] += np.float32(rng.uniform(0.2, 1.5))     # clicks: long-range time reassignment
     desc = f"case {ci}: n={n} hop={hop} rows={rows} re={reassign} S={S} frames={frames} seglen={seglen} {kw}"
     try:
-        with emspec.Engine(**kw) as e:
+        with emspec.Engine(diag=bool(seglen), **kw) as e:    # EMSPEC_SEGLEN is a switch of the diagnostic build
             fused = e.fused(n, hop, reassign)
             out = e.batch(pcm, n, hop, reassign, want=("db", "index"))
         cfg = O.make_cfg(n, hop, reassign, **kw)
