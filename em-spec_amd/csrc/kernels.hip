@@ -19,6 +19,9 @@
 #include <set>
 #include <utility>
 
+#ifndef EMSPEC_BINS_UNROLL
+#define EMSPEC_BINS_UNROLL 1
+#endif
 namespace emspec {
 
 // Kernels that need more than 64 KB of dynamic LDS must say so once per (device, kernel).  Engines on different
@@ -178,7 +181,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
     HintLookup lk;
     lk.init(seb, pl.ebin, pl.rows, pl.log_rows);
-#pragma unroll 1
+#pragma unroll EMSPEC_BINS_UNROLL
     for (int i = 0; i < 9; ++i) {
         const int k = t + T * i;
         if (k > N / 2) break;
