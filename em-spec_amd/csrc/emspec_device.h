@@ -26,16 +26,30 @@ struct PlanDev {
     int shared;          // host side only: the device is shared with a collective (engine has a communicator, world > 1)
 };
 
-// How a launch of a fused (walking) kernel cuts every stream into segments: grid = (streams, segments).  Segment g of a
-// stream covers columns [g * seglen, (g + 1) * seglen) for g < nlong, then pieces of `tail` columns.  Workgroups are
-// dispatched in linear block order, so with blockIdx.y = segment all streams' long segments start first and the
-// launch ends on the short ones: when another kernel (a collective, the gather's pack / expand) holds some CUs and the
-// workgroups no longer fill whole rounds, what is left over at the end is short.  nlong >= segments:
-// uniform segments.
-struct SegPlan { int seglen; int nlong; int tail; };
+// How a launch of a fused (walking) kernel cuts every stream into segments.
+//   uniform plan (short_last = 0): grid = (segments, streams); segment g covers columns [g * seglen, (g + 1) * seglen).
+//   shared-device plan (short_last = 1): grid = (streams, segments); segment g covers
+//     [g * seglen, (g + 1) * seglen) for g < nlong, then pieces of `tail` columns.  Workgroups are dispatched in linear
+//     block order, so with blockIdx.y = segment all streams' long segments start first and the launch ends on the
+//     short ones: when another kernel (a collective, the gather's pack / expand) holds some CUs and the workgroups no
+//     longer fill whole rounds, what is left over at the end is short.  Stream s takes the segment order rotated by s
+//     (long and short segments each among themselves).
+//   The uniform plan keeps round 1's dispatch order on purpose: with grid = (streams, segments) the N = 16384 kernel,
+//   which re-reads its 64 KB sample window every frame and relies on L2 for it, fetched 56 KB instead of 2.8 KB per
+//   column from beyond L2 (FETCH_SIZE, with and without the rotation; same speed).  The N = 4096 kernel reads every
+//   sample once and is unaffected (6.2 KB per column either way), and it is the one the N > 1 bench runs.
+struct SegPlan { int seglen; int nlong; int tail; int short_last; };
 __device__ __forceinline__ bool seg_of_block(const SegPlan& sp, int64_t C, int& s, int64_t& c0, int64_t& c1) {
+    if (!sp.short_last) {
+        s = (int)blockIdx.y;
+        c0 = (int64_t)blockIdx.x * sp.seglen;
+        c1 = (c0 + sp.seglen < C) ? c0 + sp.seglen : C;
+        return c0 < C;
+    }
     s = (int)blockIdx.x;
-    const int g = (int)blockIdx.y;
+    const int y = (int)blockIdx.y, ny = (int)gridDim.y;
+    const int nl = sp.nlong < ny ? sp.nlong : ny;
+    const int g = y < nl ? (y + s) % nl : nl + ((y - nl) + s) % (ny - nl);
     const int64_t len = g < sp.nlong ? sp.seglen : sp.tail;
     c0 = g < sp.nlong ? (int64_t)g * sp.seglen : (int64_t)sp.nlong * sp.seglen + (int64_t)(g - sp.nlong) * sp.tail;
     c1 = (c0 + len < C) ? c0 + len : C;
