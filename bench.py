@@ -435,7 +435,7 @@ def main():
             rc["valu_insts_per_column"] = prof["valu_insts_per_column"]
             rc["clock_ghz"] = prof["clock_ghz"]
             rc["clock_note"] = prof.get("clock_note")
-            rc["barrier_wait_share"] = prof.get("wait_any_share")
+            rc["wait_any_share"] = prof.get("wait_any_share")     # SQ_WAIT_ANY / SQ_WAVE_CYCLES: s_waitcnt + barrier
             rc["source"] = f"{prof['file']} (SQ counters and clock of the same launch; sources {prof['sources_sha']})"
         elif prof:
             rc["valu_util"] = None
