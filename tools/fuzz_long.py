@@ -38,7 +38,7 @@ for ci in range(cases):
         pcm[:, :: int(rng.integers(300, 5000))] += np.float32(rng.uniform(0.2, 1.5))     # clicks: long-range time reassignment
     desc = f"case {ci}: n={n} hop={hop} rows={rows} re={reassign} S={S} frames={frames} seglen={seglen} {kw}"
     try:
-        with emspec.Engine(diag=bool(seglen), **kw) as e:    # EMSPEC_SEGLEN is a switch of the diagnostic build
+        with emspec.Engine(diag=bool(seglen) or "EMSPEC_SHARED" in os.environ, **kw) as e:    # EMSPEC_SEGLEN / EMSPEC_SHARED are switches of the diagnostic build
             fused = e.fused(n, hop, reassign)
             out = e.batch(pcm, n, hop, reassign, want=("db", "index"))
         cfg = O.make_cfg(n, hop, reassign, **kw)
