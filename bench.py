@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--gather", default="lib", choices=["lib", "torch", "loopback"],
                     help="lib = libemspec's RCCL gather (default); torch = torch.distributed.gather of raw columns; "
                          "loopback = N=1 rehearsal: the rank's own columns go through pack + RCCL self send/recv + expand")
+    ap.add_argument("--root-streams", type=int, default=-1,
+                    help="N>1: streams on rank 0, which also expands the gathered columns (default: try a few splits, keep the fastest)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (torch gather via host tensors)")
     args = ap.parse_args()
@@ -262,14 +264,12 @@ def main():
         n, hop = 1024, 256
     else:
         n, hop = 4096, 256
-    S = args.streams or (1 if args.workload == "single" else 64)
+    S = args.streams or (1 if args.workload == "single" else 64)     # streams per GPU (the job has world x S)
     L = 1 << args.log2_samples
     eng = emspec.Engine(device=dev_index)
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
-    first_stream, _ = shard.stream_shard(rank, world, world * S)
-    pcm = synth_device(S, L, first_stream, dev)
-    db = torch.empty((S, C, R), dtype=torch.float32, device=dev)
+    total_streams = world * S
 
     # ---- gather set-up.  lib: libemspec's own communicator (RCCL), id handed over through torch.distributed.
     gather_mode, gather_note = "none", None
@@ -288,102 +288,153 @@ def main():
         eng.comm_init(emspec.comm_unique_id(), 0, 1)
         gather_mode = "lib"
     gathering = gather_mode != "none"
-
-    # N>1: two index buffers, so the gather of step k's last chunk overlaps step k+1's first kernels
-    nbuf = 2 if gathering else 1
-    idx_bufs = [torch.empty((S, C, R), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    idx = idx_bufs[0]
-    nch = max(1, min(args.chunks, S)) if gathering else max(1, min(args.force_chunks, S)) if args.force_chunks else 1
-    bounds = [(S * i // nch, S * (i + 1) // nch) for i in range(nch)]
+    cur = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if gathering else None
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gworld = max(world, 1)
-    gathered = None
-    if gathering and rank == 0:
-        if gather_mode == "lib":      # [chunk] -> [world, streams of the chunk, C, R]
-            gathered = [torch.empty((gworld, b - a, C, R), dtype=torch.uint8, device=dev) for a, b in bounds]
-        else:
-            gathered = [[torch.empty((b - a, C, R), dtype=torch.uint8, device=gdev) for _ in range(world)] for a, b in bounds]
-
-    cur = torch.cuda.current_stream(dev)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    sent = [[None] * nch for _ in range(nbuf)]     # per (buffer, chunk): event after its last gather
-    nstep = [0]
-    pending = []                                   # (buffer index, chunk index, ready event): computed, not yet gathered
-    wire_bytes = [0, 0]                            # packed bytes this rank sent, columns they carried
-
-    def do_gather(p, ci, ready):
-        a, b = bounds[ci]
-        ibuf = idx_bufs[p]
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ready)
-            if gather_mode == "lib":
-                # pack + size exchange + send/recv + expand on comm_stream; the call synchronises comm_stream once, while
-                # the next chunk's kernels (already enqueued on the compute stream) keep the GPU busy
-                nb = eng.gather_columns(ibuf[a:b], root=0, out=gathered[ci] if rank == 0 else None, stream=comm_stream,
-                                        loopback=(world == 1))
-                wire_bytes[0] += nb
-                wire_bytes[1] += (b - a) * C if nb else 0
-            else:
-                src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
-                shard.gather_columns_into(src, gathered[ci] if rank == 0 else None, dst=0)
-            sent[p][ci] = torch.cuda.Event()
-            sent[p][ci].record(comm_stream)
-
-    def step(timed_i=None):
-        p = nstep[0] % nbuf
-        nstep[0] += 1
-        ibuf = idx_bufs[p]
-        for ci, (a, b) in enumerate(bounds):
-            if sent[p][ci] is not None:
-                cur.wait_event(sent[p][ci])        # the gather that last read this chunk of ibuf
-            if timed_i is not None and ci == 0:
-                kev[timed_i][0].record(cur)
-            eng.batch_device(pcm[a:b], n, hop, bool(args.reassign), db=db[a:b], index=ibuf[a:b], stream=cur)
-            if timed_i is not None and ci == nch - 1:
-                kev[timed_i][1].record(cur)
-            if gathering:
-                ready = torch.cuda.Event()
-                ready.record(cur)
-                # gather the PREVIOUS chunk now that this one is enqueued behind it: the host may block in there
-                while pending:
-                    do_gather(*pending.pop(0))
-                pending.append((p, ci, ready))
-
-    def flush():
-        while pending:
-            do_gather(*pending.pop(0))
+    nbuf = 2 if gathering else 1       # N>1: two index buffers, so the gather of step k's last chunk overlaps step k+1's first kernels
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    class Job:
+        """This rank's shard of the job for one split of the streams (counts[r] streams on rank r): buffers, the
+        chunked step and the pipelined gather."""
+
+        def __init__(self, counts):
+            self.counts = list(counts)
+            self.uneven = len(set(counts)) > 1
+            firsts = shard.first_streams(counts)
+            Sl = self.S = counts[rank]
+            self.pcm = synth_device(Sl, L, firsts[rank], dev)
+            self.db = torch.empty((Sl, C, R), dtype=torch.float32, device=dev)
+            self.idx_bufs = [torch.empty((Sl, C, R), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            nch = max(1, min(args.chunks, min(counts))) if gathering else (max(1, min(args.force_chunks, Sl)) if args.force_chunks else 1)
+            self.nch = nch
+            chunk = lambda Sx: [(Sx * i // nch, Sx * (i + 1) // nch) for i in range(nch)]     # the same rule on every rank
+            self.bounds = chunk(Sl)
+            self.gathered = None
+            if gathering and rank == 0:
+                per_rank = [chunk(c) for c in counts]
+                if gather_mode == "lib":      # [chunk] -> the ranks' blocks [streams of the chunk, C, R] one after the other
+                    self.gathered = [torch.empty((sum(pr[ci][1] - pr[ci][0] for pr in per_rank), C, R), dtype=torch.uint8, device=dev)
+                                     for ci in range(nch)]
+                else:
+                    self.gathered = [[torch.empty((pr[ci][1] - pr[ci][0], C, R), dtype=torch.uint8, device=gdev) for pr in per_rank]
+                                     for ci in range(nch)]
+            self.sent = [[None] * nch for _ in range(nbuf)]     # per (buffer, chunk): event after its last gather
+            self.nstep = 0
+            self.pending = []                                   # (buffer index, chunk index, ready event): computed, not yet gathered
+            self.wire_bytes = [0, 0]                            # packed bytes this rank sent, columns they carried
+            self.kev = []
+
+        def do_gather(self, p, ci, ready):
+            a, b = self.bounds[ci]
+            ibuf = self.idx_bufs[p]
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready)
+                if gather_mode == "lib":
+                    # pack + size exchange + send/recv + expand on comm_stream; the call synchronises comm_stream once, while
+                    # the next chunk's kernels (already enqueued on the compute stream) keep the GPU busy
+                    nb = eng.gather_columns(ibuf[a:b], root=0, out=self.gathered[ci] if rank == 0 else None, stream=comm_stream,
+                                            loopback=(world == 1))
+                    self.wire_bytes[0] += nb
+                    self.wire_bytes[1] += (b - a) * C if nb else 0
+                else:
+                    src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
+                    shard.gather_columns_into(src, self.gathered[ci] if rank == 0 else None, dst=0, uneven=self.uneven)
+                self.sent[p][ci] = torch.cuda.Event()
+                self.sent[p][ci].record(comm_stream)
+
+        def step(self, timed=False):
+            p = self.nstep % nbuf
+            self.nstep += 1
+            ibuf = self.idx_bufs[p]
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+            for ci, (a, b) in enumerate(self.bounds):
+                if self.sent[p][ci] is not None:
+                    cur.wait_event(self.sent[p][ci])        # the gather that last read this chunk of ibuf
+                if timed and ci == 0:
+                    ev[0].record(cur)
+                eng.batch_device(self.pcm[a:b], n, hop, bool(args.reassign), db=self.db[a:b], index=ibuf[a:b], stream=cur)
+                if timed and ci == self.nch - 1:
+                    ev[1].record(cur)
+                if gathering:
+                    ready = torch.cuda.Event()
+                    ready.record(cur)
+                    # gather the PREVIOUS chunk now that this one is enqueued behind it: the host may block in there
+                    self.flush()
+                    self.pending.append((p, ci, ready))
+            if timed:
+                self.kev.append(ev)
+
+        def flush(self):
+            while self.pending:
+                self.do_gather(*self.pending.pop(0))
+
+        def run(self, steps, timed=False):
+            """barrier, `steps` steps (and the gathers they owe), barrier; returns the elapsed seconds, max over ranks."""
+            self.wire_bytes[:] = [0, 0]
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(timed)
+            self.flush()
+            barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([el], dtype=torch.float64, device=gdev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            return el
+
     if world > 1 and gather_mode == "torch":
         # open the point-to-point connections the gather uses before anything is timed
         probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
         shard.gather_columns_into(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+
+    # ---- how the streams are split over the ranks.  Rank 0 also receives and expands the other ranks' columns, so with
+    # equal shards it is the slowest rank and every other GPU waits for it; a lighter shard for rank 0 evens that out.
+    # How much lighter depends on what the expand and RCCL's receive kernels cost beside the column kernel on the
+    # root, which only an N-GPU run shows - so a few splits are tried for three steps each and the fastest is kept.
+    counts = [S] * world
+    split_trials = None
+    if world > 1 and gathering and args.root_streams >= 0:
+        counts = shard.root_light_counts(world, total_streams, 0, max(args.root_streams, args.chunks))
+    elif world > 1 and gathering and S >= 16:
+        split_trials = []
+        warm = Job(counts)             # connections, code objects and the allocator's pools: paid before any split is timed
+        warm.run(2)
+        del warm
+        for other in sorted({S, S + S // 32, S + S // 16, S + 3 * S // 32, S + S // 8}):
+            root_count = total_streams - (world - 1) * other
+            if root_count < max(1, args.chunks):
+                continue
+            trial = shard.root_light_counts(world, total_streams, 0, root_count)
+            job = Job(trial)
+            job.run(1)                                     # the first gather of a run opens RCCL's connections
+            el = job.run(3)
+            split_trials.append({"streams_per_rank": trial, "columns_per_s": total_streams * C * 3 / el})
+            del job
+        best = max(split_trials, key=lambda t: t["columns_per_s"])   # the same numbers on every rank (max-reduced times)
+        counts = best["streams_per_rank"]
+
+    job = Job(counts)
     for _ in range(max(args.warmup, 1 if gathering else 0)):   # the first gather opens RCCL's connections: never timed
-        step()
-    flush()
-    wire_bytes[:] = [0, 0]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    flush()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        job.step()
+    job.flush()
+    elapsed = job.run(args.steps, timed=True)
+    wire_bytes = job.wire_bytes
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
         wb = torch.tensor(wire_bytes, dtype=torch.float64, device=gdev)
         dist.all_reduce(wb, op=dist.ReduceOp.SUM)
         wire_bytes = [float(wb[0].item()), float(wb[1].item())]
+    S_nominal = S
+    S, pcm, db, idx, nch, kev = job.S, job.pcm, job.db, job.idx_bufs[0], job.nch, job.kev   # rank 0's shard, for the roofline below
 
     if rank == 0:
-        cols_per_step = world * S * C
+        cols_per_step = total_streams * C
         value = cols_per_step * args.steps / elapsed
         # dominant-kernel roofline: algorithmic bytes per column for this output mode
         # (SURVEY.md §8d: 4*hop in, + 4*R dB out, + R palette-index out)
@@ -400,7 +451,7 @@ def main():
         rf["traffic"] = prof["hbm_bytes_per_launch"] if (prof and fresh and "hbm_bytes_per_launch" in prof) else None
         rf["traffic_source"] = (f"{prof['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; sources {prof['sources_sha']}"
                                 f"{'' if fresh else ', STALE: kernels changed since, traffic withheld'})") if prof else None
-        wl = (f"{S} concurrent 48 kHz streams per GPU x 2^{args.log2_samples} samples, FFT {n}, hop {hop}, reassignment "
+        wl = (f"{S_nominal} concurrent 48 kHz streams per GPU x 2^{args.log2_samples} samples, FFT {n}, hop {hop}, reassignment "
               f"{'ON' if args.reassign else 'OFF'}, {R} log-frequency rows, outputs float32 dB + uint8 palette index")
         if gathering:
             wl += (f"; gather of the palette-index columns to rank 0 in {nch} overlapped chunks per step by "
@@ -412,13 +463,13 @@ def main():
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl, "streams_per_gpu": S, "samples_per_stream": L, "columns_per_step": cols_per_step,
+            "config": {"workload": wl, "streams_per_gpu": S_nominal, "streams_per_rank": counts, "samples_per_stream": L, "columns_per_step": cols_per_step,
                        "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True),
                        "sources_sha": sources_sha()},
             "roofline": rf,
         }
         if gathering:
-            line["gather"] = {"path": gather_mode, "note": gather_note, "chunks_per_step": nch,
+            line["gather"] = {"path": gather_mode, "note": gather_note, "chunks_per_step": nch, "split_trials": split_trials,
                               "wire_bytes_per_column": (wire_bytes[0] / wire_bytes[1]) if wire_bytes[1] else None,
                               "raw_bytes_per_column": R}
         # the bounds this kernel really sits under (it is not HBM-bound: SURVEY.md §8(d) consistency warning)

@@ -41,7 +41,7 @@ struct emspec_comm_state {
     uint8_t* d_wire = nullptr; size_t wire_bytes = 0;        // this rank's packed image
     void* d_scratch = nullptr; size_t scratch_bytes = 0;     // pack / unpack scan workspace
     uint8_t* d_recv = nullptr; size_t recv_bytes = 0;        // root: the other ranks' images, back to back
-    uint64_t* d_sizes = nullptr;                             // [world] image sizes after the all-gather
+    uint64_t* d_sizes = nullptr;                             // [world][2] (image bytes, columns) after the all-gather
     uint64_t* h_sizes = nullptr;                             // page-locked copy
 };
 
@@ -105,8 +105,8 @@ int emspec_comm_init(emspec_engine* e, const uint8_t* id_bytes, int32_t rank, in
     NCCLCHK(e, ncclCommInitRank(&c->comm, world, id, rank));
     c->rank = rank;
     c->world = world;
-    HIPCHK(e, hipMalloc(&c->d_sizes, sizeof(uint64_t) * (size_t)(world + 1)));
-    HIPCHK(e, hipHostMalloc((void**)&c->h_sizes, sizeof(uint64_t) * (size_t)(world + 1), hipHostMallocDefault));
+    HIPCHK(e, hipMalloc(&c->d_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1)));
+    HIPCHK(e, hipHostMalloc((void**)&c->h_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1), hipHostMallocDefault));
     return EMSPEC_OK;
 }
 
@@ -168,7 +168,7 @@ int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_b
 }
 
 int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t columns, int32_t root, uint8_t* gathered_dev,
-                          uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent) {
+                          int64_t gathered_capacity, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent) {
     if (!e || !index_dev || columns < 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument / no columns");
     emspec_comm_state* c = e->comm;
     if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first");
@@ -184,6 +184,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     const bool i_send = !is_root || loopback;
     int rc;
     if (wire_bytes_sent) *wire_bytes_sent = 0;
+    c->h_sizes[2 * world] = (uint64_t)columns;   // page-locked: read by the async copy below
 
     // ---- this rank's wire image
     uint64_t* d_total = nullptr;
@@ -196,40 +197,50 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
         d_total = wire_total_ptr(c->d_scratch, columns);
         HIPCHK(e, hipMemsetAsync(d_total, 0, sizeof(uint64_t), st));   // the root sends nothing
     }
-    // ---- everybody learns everybody's image size (RCCL counts must match on both sides of a send/recv)
-    NCCLCHK(e, ncclAllGather(d_total, c->d_sizes, 1, ncclUint64, c->comm, st));
-    HIPCHK(e, hipMemcpyAsync(c->h_sizes, c->d_sizes, sizeof(uint64_t) * (size_t)world, hipMemcpyDeviceToHost, st));
+    // ---- everybody learns everybody's image size and column count (RCCL counts must match on both sides of a
+    // send/recv; shards may differ in size: a host that gives the root fewer streams balances its extra expand work)
+    HIPCHK(e, hipMemcpyAsync(d_total + 1, &c->h_sizes[2 * world], sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    NCCLCHK(e, ncclAllGather(d_total, c->d_sizes, 2, ncclUint64, c->comm, st));
+    HIPCHK(e, hipMemcpyAsync(c->h_sizes, c->d_sizes, sizeof(uint64_t) * 2 * (size_t)world, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));
-    const uint64_t bound = (uint64_t)wire_bound_bytes(columns, R);
-    for (int r = 0; r < world; ++r)
-        if (c->h_sizes[r] > bound) return fail(e, EMSPEC_ERR_COMM, "a rank announced a wire image larger than its bound (ranks disagree on the column count?)");
-    if (wire_bytes_sent) *wire_bytes_sent = (int64_t)c->h_sizes[me];
+    for (int r = 0; r < world; ++r) {
+        const uint64_t bytes_r = c->h_sizes[2 * r], cols_r = c->h_sizes[2 * r + 1];
+        if (cols_r < 1 || cols_r * (uint64_t)R >= (1ull << 32) || bytes_r > (uint64_t)wire_bound_bytes((int64_t)cols_r, R))
+            return fail(e, EMSPEC_ERR_COMM, "a rank announced an impossible wire image (column count / size)");
+    }
+    if (wire_bytes_sent) *wire_bytes_sent = (int64_t)c->h_sizes[2 * me];
 
     // ---- the exchange: one grouped set of point-to-point transfers, every rank -> root
-    std::vector<size_t> off((size_t)world + 1, 0);
+    std::vector<size_t> off((size_t)world + 1, 0), dst_off((size_t)world + 1, 0);
     if (is_root) {
-        for (int r = 0; r < world; ++r) off[r + 1] = off[r] + (((size_t)c->h_sizes[r] + 255) & ~(size_t)255);
+        for (int r = 0; r < world; ++r) {
+            off[r + 1] = off[r] + (((size_t)c->h_sizes[2 * r] + 255) & ~(size_t)255);
+            dst_off[r + 1] = dst_off[r] + (size_t)c->h_sizes[2 * r + 1] * R;
+        }
+        if (dst_off[world] > (size_t)(gathered_capacity > 0 ? gathered_capacity : 0))
+            return fail(e, EMSPEC_ERR_INVALID_ARG, "the gathered buffer is smaller than the shards the ranks announced");
         if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc;
     }
     NCCLCHK(e, ncclGroupStart());
     ncclResult_t nr = ncclSuccess;
-    if (i_send && c->h_sizes[me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[me], ncclUint8, root, c->comm, st);
+    if (i_send && c->h_sizes[2 * me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[2 * me], ncclUint8, root, c->comm, st);
     if (is_root)
         for (int r = 0; r < world && nr == ncclSuccess; ++r)
-            if (c->h_sizes[r] > 0) nr = ncclRecv(c->d_recv + off[r], (size_t)c->h_sizes[r], ncclUint8, r, c->comm, st);
+            if (c->h_sizes[2 * r] > 0) nr = ncclRecv(c->d_recv + off[r], (size_t)c->h_sizes[2 * r], ncclUint8, r, c->comm, st);
     const ncclResult_t ge = ncclGroupEnd();
     if (nr != ncclSuccess) return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr));
     NCCLCHK(e, ge);
 
-    // ---- root: expand every image into its rank's block of the gathered buffer; its own columns are a device copy
+    // ---- root: expand every image into its rank's block of the gathered buffer (blocks in rank order, each as long as
+    // that rank's shard); its own columns are a device copy
     if (is_root) {
         for (int r = 0; r < world; ++r) {
-            uint8_t* dst = gathered_dev + (size_t)r * col_bytes;
+            uint8_t* dst = gathered_dev + dst_off[r];
             if (r == me && !loopback) {
                 if (dst != index_dev) HIPCHK(e, hipMemcpyAsync(dst, index_dev, col_bytes, hipMemcpyDeviceToDevice, st));
                 continue;
             }
-            HIPCHK(e, launch_wire_unpack(c->d_recv + off[r], columns, R, dst, st));
+            HIPCHK(e, launch_wire_unpack(c->d_recv + off[r], (int64_t)c->h_sizes[2 * r + 1], R, dst, st));
         }
     }
     return EMSPEC_OK;
@@ -259,7 +270,7 @@ int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L
     uint8_t* d_all = is_root ? (uint8_t*)base : nullptr;
     HIPCHK(e, hipMemcpyAsync(d_pcm, pcm, (size_t)S * L * 4, hipMemcpyHostToDevice, e->stream));
     if ((rc = emspec_batch_device(e, d_pcm, S, L, n, hop, reassign, d_db, nullptr, d_idx, e->stream))) return rc;
-    if ((rc = emspec_gather_columns(e, d_idx, (int64_t)S * C, root, d_all, 0, e->stream, wire_bytes_sent))) return rc;
+    if ((rc = emspec_gather_columns(e, d_idx, (int64_t)S * C, root, d_all, (int64_t)(cells * c->world), 0, e->stream, wire_bytes_sent))) return rc;
     if (db_local) HIPCHK(e, hipMemcpyAsync(db_local, d_db, cells * 4, hipMemcpyDeviceToHost, e->stream));
     if (is_root) HIPCHK(e, hipMemcpyAsync(gathered_index, d_all, cells * c->world, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));

@@ -103,8 +103,8 @@ def load(diag=False):
     lib.emspec_comm_destroy.argtypes = [C.c_void_p]
     lib.emspec_comm_rank.argtypes = [C.c_void_p]
     lib.emspec_comm_world.argtypes = [C.c_void_p]
-    lib.emspec_gather_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                          C.POINTER(C.c_int64)]
+    lib.emspec_gather_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_uint32,
+                                          C.c_void_p, C.POINTER(C.c_int64)]
     lib.emspec_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.emspec_wire_bound.restype = C.c_int64
@@ -316,18 +316,18 @@ class Engine:
 
     def gather_columns(self, index_t, root=0, out=None, stream=None, loopback=False):
         """index_t: contiguous uint8 CUDA tensor [..., rows] of this rank's finished columns; out (root only):
-        uint8 CUDA tensor [world, ...same shape...].  Returns the bytes this rank put on the wire."""
+        uint8 CUDA tensor holding the ranks' blocks in rank order ([world, ...same shape...] when the shards are equal;
+        the library checks that the announced shards fit).  Returns the bytes this rank put on the wire."""
         import torch
         assert index_t.is_cuda and index_t.dtype == torch.uint8 and index_t.is_contiguous() and index_t.shape[-1] == self.rows
         columns = index_t.numel() // self.rows
         st = stream if stream is not None else torch.cuda.current_stream(index_t.device)
         if out is not None:
             assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous()
-            assert self.comm_world <= 0 or out.numel() == self.comm_world * index_t.numel()
         sent = C.c_int64(0)
         self._chk(self._lib.emspec_gather_columns(self._h, C.c_void_p(index_t.data_ptr()), columns, root,
                                                   C.c_void_p(out.data_ptr()) if out is not None else None,
-                                                  GATHER_LOOPBACK if loopback else 0, C.c_void_p(st.cuda_stream), C.byref(sent)))
+                                                  out.numel() if out is not None else 0, GATHER_LOOPBACK if loopback else 0, C.c_void_p(st.cuda_stream), C.byref(sent)))
         return int(sent.value)
 
     def batch_gather(self, pcm, n, hop, reassign=True, root=0, want_db=False):

@@ -19,6 +19,33 @@ def stream_shard(rank, world, total_streams):
     return first, count
 
 
+def root_light_counts(world, total_streams, root, root_count):
+    """Shard sizes when `root` takes root_count streams and the other ranks split the rest as evenly as they can (the
+    remainder goes to the lowest of them).  The root also receives and expands every other rank's columns, so an equal
+    split makes it the slowest rank; bench.py tries a few of these splits and keeps the fastest."""
+    if world == 1:
+        return [total_streams]
+    root_count = max(0, min(int(root_count), total_streams))
+    base, rem = divmod(total_streams - root_count, world - 1)
+    counts, k = [], 0
+    for r in range(world):
+        if r == root:
+            counts.append(root_count)
+        else:
+            counts.append(base + (1 if k < rem else 0))
+            k += 1
+    return counts
+
+
+def first_streams(counts):
+    """Index of each rank's first stream for shard sizes `counts`."""
+    out, acc = [], 0
+    for c in counts:
+        out.append(acc)
+        acc += c
+    return out
+
+
 def gather_columns(local, dst=0, group=None):
     """Gather every rank's finished columns [S_local, C, R(,4)] to `dst`, in stream order.
     Returns the concatenated tensor on dst, None elsewhere.  All ranks must hold the same S_local."""
@@ -31,9 +58,22 @@ def gather_columns(local, dst=0, group=None):
     return torch.cat(bufs, dim=0) if rank == dst else None
 
 
-def gather_columns_into(local, out_list, dst=0, group=None):
-    """Same, into preallocated per-rank buffers (out_list on dst, None elsewhere): no allocation in the timed path."""
-    dist.gather(local, out_list if dist.get_rank(group) == dst else None, dst=dst, group=group)
+def gather_columns_into(local, out_list, dst=0, group=None, uneven=False):
+    """Same, into preallocated per-rank buffers (out_list on dst, None elsewhere): no allocation in the timed path.
+    uneven=True: the ranks' shards differ in size (every rank must pass the same flag), so the gather is posted as
+    point-to-point transfers; a rank with an empty shard takes no part."""
+    rank = dist.get_rank(group)
+    if not uneven:
+        dist.gather(local, out_list if rank == dst else None, dst=dst, group=group)
+        return
+    if rank == dst:
+        reqs = [dist.irecv(buf, src=r, group=group) for r, buf in enumerate(out_list) if r != dst and buf.numel()]
+        if local.numel():
+            out_list[dst].copy_(local)
+        for q in reqs:
+            q.wait()
+    elif local.numel():
+        dist.send(local, dst=dst, group=group)
 
 
 def comm_setup(engine, rank, world, group=None):

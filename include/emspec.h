@@ -244,10 +244,11 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
  * audio streams shard embarrassingly across the 8 GPUs of one node with a single RCCL gather over xGMI to collect
  * finished columns").  The reference has no GPU path and no collectives: [BUILD-DEFINED].
  *
- * One process (or thread) per GPU, each with its own engine.  The host splits the streams into equal shards, every
- * rank runs emspec_batch_device on its shard (no exchange during compute), then all ranks call
- * emspec_gather_columns: the palette-index columns (uint8, 1 byte per cell - the float32 dB columns stay on the
- * producing GPU) of every rank arrive on `root` as gathered[world][columns][rows], rank-major.
+ * One process (or thread) per GPU, each with its own engine.  The host splits the streams into shards (equal, or a
+ * smaller one for the root, which also expands what it receives), every rank runs emspec_batch_device on its shard
+ * (no exchange during compute), then all ranks call emspec_gather_columns: the palette-index columns (uint8, 1 byte
+ * per cell - the float32 dB columns stay on the producing GPU) of every rank arrive on `root`, the ranks' blocks
+ * [columns_r][rows] one after the other in rank order.
  *
  * Rank 0 obtains an id with emspec_comm_unique_id and hands its 128 bytes to the other ranks by whatever channel
  * the host has (Node: IPC / a file; Python: torch.distributed's store); every rank then calls emspec_comm_init
@@ -262,8 +263,10 @@ int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator
 
 /*
  * Collective over the engine's communicator.  index_dev: this rank's finished palette-index columns
- * [columns][rows] on its device (columns = streams * columns-per-stream of the shard; the same on every rank).
- * gathered_dev (root only; ignored elsewhere): [world][columns][rows] on the root's device.
+ * [columns][rows] on its device (columns = streams * columns-per-stream of the shard; ranks may differ).
+ * gathered_dev (root only; ignored elsewhere): the ranks' blocks in rank order on the root's device, sum(columns_r) *
+ * rows bytes; gathered_capacity = the bytes available there (the call fails with EMSPEC_ERR_INVALID_ARG on the root
+ * before writing anything if the announced shards do not fit).
  * xGMI is point-to-point - each rank reaches the root over one link - so the columns travel as a lossless packed
  * image (per-column offset + bit mask of the non-zero cells + their indices; emspec_wire_* below) and are expanded on the root.
  * The call enqueues everything on hip_stream and synchronises that stream ONCE (the packed sizes differ per rank
@@ -275,7 +278,8 @@ int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator
  */
 #define EMSPEC_GATHER_LOOPBACK 1u
 int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t columns, int32_t root,
-                          uint8_t* gathered_dev, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent);
+                          uint8_t* gathered_dev, int64_t gathered_capacity, uint32_t flags, void* hip_stream,
+                          int64_t* wire_bytes_sent);
 
 /*
  * Host-buffer convenience for a rank process (the N-API addon's computeColumnsGather): this rank's S streams

@@ -67,3 +67,57 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     _, _, idx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",), threads=1)
     assert got.shape == idx.shape
     assert np.array_equal(got, idx)
+
+
+def test_root_light_split():
+    """A lighter shard for the collecting rank (bench.py's N>1 split): the counts cover every stream exactly once."""
+    sys.path.insert(0, os.path.join(ROOT, "em-spec_amd"))
+    from emspec import shard
+    assert shard.root_light_counts(8, 512, 0, 64) == [64] * 8
+    assert shard.root_light_counts(8, 512, 0, 36) == [36] + [68] * 7
+    assert shard.root_light_counts(8, 512, 0, 8) == [8] + [72] * 7
+    assert shard.root_light_counts(4, 256, 0, 50) == [50, 69, 69, 68]
+    assert shard.root_light_counts(4, 256, 2, 40) == [72, 72, 40, 72]
+    assert shard.root_light_counts(1, 64, 0, 3) == [64]
+    for world, total, rc in ((2, 128, 56), (3, 10, 1), (8, 512, 22)):
+        counts = shard.root_light_counts(world, total, 0, rc)
+        assert sum(counts) == total and counts[0] == rc and max(counts[1:]) - min(counts[1:]) <= 1
+        firsts = shard.first_streams(counts)
+        assert firsts[0] == 0 and all(firsts[r + 1] == firsts[r] + counts[r] for r in range(world - 1))
+
+
+def _uneven_worker(rank, world, port, counts, out_path):
+    for p in (ROOT, os.path.join(ROOT, "em-spec_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import oracle as O
+    from emspec import shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, hop, frames = 1024, 256, 12
+    first = shard.first_streams(counts)[rank]
+    pcm = synth.streams(counts[rank], n + hop * (frames - 1), first=first)
+    _, _, idx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",), threads=1)
+    local = torch.from_numpy(idx)
+    bufs = [torch.empty((c,) + tuple(local.shape[1:]), dtype=torch.uint8) for c in counts] if rank == 0 else None
+    for _ in range(2):                                    # twice: the second gather reuses the buffers, as bench.py does
+        shard.gather_columns_into(local, bufs, dst=0, uneven=True)
+    if rank == 0:
+        np.save(out_path, torch.cat(bufs, dim=0).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_uneven_gather_matches_single_process(tmp_path):
+    """Shards of different size (1 stream on the collecting rank, 3 on the other) arrive in stream order."""
+    import oracle as O
+    from emspec import synth
+    out = str(tmp_path / "gathered_uneven.npy")
+    counts = [1, 3]
+    mp.spawn(_uneven_worker, args=(2, _free_port(), counts, out), nprocs=2, join=True)
+    got = np.load(out)
+    n, hop, frames = 1024, 256, 12
+    pcm = synth.streams(sum(counts), n + hop * (frames - 1))
+    _, _, idx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",), threads=1)
+    assert got.shape == idx.shape and np.array_equal(got, idx)

@@ -87,6 +87,13 @@ def test_rccl_gather_one_rank_loopback():
         with pytest.raises(emspec.EmspecError) as ei:
             e.comm_init(emspec.comm_unique_id(), 0, 1)
         assert ei.value.code == emspec.ERR_STATE
+        # a gathered buffer smaller than the announced shards is refused before anything is written
+        small = torch.full((S * frames * e.rows - 1,), 0x5A, dtype=torch.uint8, device=dev)
+        with pytest.raises(emspec.EmspecError) as ei:
+            e.gather_columns(idx, root=0, out=small, loopback=True)
+        assert ei.value.code == emspec.ERR_INVALID_ARG
+        torch.cuda.synchronize()
+        assert bool((small == 0x5A).all())
         _, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",))
         d = np.abs(out[0].cpu().numpy().astype(int) - oidx.astype(int))
         assert d.max() <= 1 and np.mean(d != 0) < 1e-3
