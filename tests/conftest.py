@@ -13,9 +13,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _torch_first():
+    """torch must have initialised its HIP runtime before libemspec.so creates an engine: in the other order torch
+    finds no device afterwards ("No HIP GPUs are available").  The tests that use torch tensors come after others that
+    only need the engine, so the engine fixtures settle the order."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def engine():
     """One libemspec engine on cuda:0 for the whole GPU session (no CPU fallback exists)."""
+    _torch_first()
     import emspec
     e = emspec.Engine()
     yield e
@@ -25,6 +38,7 @@ def engine():
 @pytest.fixture(scope="session")
 def diag_engine():
     """Engine of libemspec_diag.so (the product sources + include/emspec_debug.h), for tests that probe internals."""
+    _torch_first()
     import emspec
     e = emspec.Engine(diag=True)
     yield e
