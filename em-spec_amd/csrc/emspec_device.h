@@ -107,8 +107,15 @@ __device__ __forceinline__ void fft_stages(float2 (&v)[1 << R], int lo, const fl
             if constexpr (B0 == 0) {
                 // last pass: lo == 0, q is a compile-time constant
                 const int q = (i & (mloc - 1)) << s;
+                // tw[N/8] = (c, -c) and tw[3N/8] = (-c, -c) with c = float(cos(pi/4)) in every table (emspec_create builds
+                // the second quarter from the first by the quarter-turn symmetry; tests/test_oracle.py pins the value):
+                // as literals they cost no load - from the table they were two vector loads per frame, pl.tw not being
+                // provably read-only
+                constexpr float kC8 = 0.70710677f;
                 if (q == 0) v[i + mloc] = d;
                 else if (q == N / 4) v[i + mloc] = make_float2(d.y, -d.x);
+                else if (q == N / 8) v[i + mloc] = cmul_tw(d, make_float2(kC8, -kC8));
+                else if (q == 3 * (N / 8)) v[i + mloc] = cmul_tw(d, make_float2(-kC8, -kC8));
                 else v[i + mloc] = cmul_tw(d, tw[q]);
             } else {
                 const int q = (((i & (mloc - 1)) << B0) + lo) << s;
@@ -200,6 +207,16 @@ struct HintLookup {
     __device__ __forceinline__ int row_signed(float kh) const {
         if (wtop) return in_range(kh) ? row_unchecked(kh) : -1;
         return row_unchecked(kh);
+    }
+    // row_signed for a table the caller KNOWS is log-spaced (wtop == 0): no branch, so the lookups of a thread's
+    // consecutive bins stay in one basic block and their table reads are issued together
+    __device__ __forceinline__ int row_signed_log(float kh) const {
+        int r0 = (int)((__log2f(kh) - l2e0) * rscale);
+        r0 = max(0, min(r0, R - 1));
+        const float lo = eb[r0], hi = eb[r0 + 1];
+        r0 += (kh >= hi) ? 1 : 0;
+        r0 -= (kh < lo) ? 1 : 0;
+        return r0;
     }
     __device__ __forceinline__ int operator()(float kh) const { return in_range(kh) ? row_unchecked(kh) : -1; }
 };

@@ -145,6 +145,10 @@ def test_twiddle_table_is_what_libm_gives_and_quarter_turn_symmetric(n):
     assert np.array_equal(tw.reshape(-1, 2), direct)
     c, s = tw[0::2], tw[1::2]
     assert np.array_equal(c[n // 4:], s[:n // 4]) and np.array_equal(s[n // 4 + 1:], -c[1:n // 4])
+    # the kernels' last pass carries these two entries as literals (emspec_device.h fft_stages, kC8)
+    c8 = np.float32(0.70710677)
+    assert c8.view(np.uint32) == 0x3F3504F3
+    assert (c[n // 8], s[n // 8]) == (c8, -c8) and (c[3 * n // 8], s[3 * n // 8]) == (-c8, -c8)
 
 
 @pytest.mark.parametrize("n,hop,reassign", [(4096, 256, True), (1024, 256, False), (16384, 512, True), (2048, 128, True),

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""A/B two builds of libemspec.so on the same box: alternates them (child process each), times the column kernel of a
+bench workload with HIP events, prints ms per launch.  Box-to-box spread is ~2 %, so variants are compared here.
+   python tools/ab_kernel.py libA.so libB.so [--workload batch64|n16384] [--rounds 3]
+"""
+import argparse, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "em-spec_amd")]
+import torch
+import emspec
+emspec.LIB_PATH = %(lib)r
+from bench import synth_device, time_launches
+n, hop = %(n)d, %(hop)d
+dev = torch.device("cuda", 0)
+eng = emspec.Engine()
+S, L = 64, 1 << 22
+C = emspec.num_columns(L, n, hop)
+pcm = synth_device(S, L, 0, dev)
+db = torch.empty((S, C, eng.rows), dtype=torch.float32, device=dev)
+idx = torch.empty((S, C, eng.rows), dtype=torch.uint8, device=dev)
+cur = torch.cuda.current_stream(dev)
+ms = time_launches(lambda: eng.batch_device(pcm, n, hop, True, db=db, index=idx, stream=cur), cur, %(reps)d)
+print(f"{ms:.4f}")
+'''
+
+ap = argparse.ArgumentParser()
+ap.add_argument("libs", nargs="+")
+ap.add_argument("--workload", default="batch64")
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--n", type=int, default=0, help="FFT size (overrides --workload)")
+ap.add_argument("--hop", type=int, default=0)
+a = ap.parse_args()
+n, hop, reps = (16384, 512, 4) if a.workload == "n16384" else (4096, 256, 8)
+if a.n:
+    n, hop, reps = a.n, a.hop or n // 4, 6
+res = {l: [] for l in a.libs}
+for r in range(a.rounds):
+    for lib in a.libs:
+        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps)],
+                             capture_output=True, text=True, timeout=300)
+        if out.returncode != 0:
+            sys.exit(out.stderr[-2000:])
+        res[lib].append(float(out.stdout.strip().splitlines()[-1]))
+        print(f"round {r} {os.path.basename(lib)}: {res[lib][-1]:.3f} ms", flush=True)
+for lib in a.libs:
+    v = res[lib]
+    print(f"{os.path.basename(lib):32s} min {min(v):.3f}  mean {sum(v) / len(v):.3f} ms")
