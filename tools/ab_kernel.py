@@ -23,6 +23,8 @@ db = torch.empty((S, C, eng.rows), dtype=torch.float32, device=dev)
 idx = torch.empty((S, C, eng.rows), dtype=torch.uint8, device=dev)
 cur = torch.cuda.current_stream(dev)
 ms = time_launches(lambda: eng.batch_device(pcm, n, hop, True, db=db, index=idx, stream=cur), cur, %(reps)d)
+torch.cuda.synchronize()
+print(f"checksum idx {int(idx.sum(dtype=torch.int64).item())} db {float(db.double().sum().item()):.6e}", file=sys.stderr)
 print(f"{ms:.4f}")
 '''
 
@@ -44,6 +46,9 @@ for r in range(a.rounds):
         if out.returncode != 0:
             sys.exit(out.stderr[-2000:])
         res[lib].append(float(out.stdout.strip().splitlines()[-1]))
+        chk = [l for l in out.stderr.splitlines() if l.startswith("checksum")]
+        if r == 0 and chk:
+            print(f"  {os.path.basename(lib)}: {chk[-1]}")
         print(f"round {r} {os.path.basename(lib)}: {res[lib][-1]:.3f} ms", flush=True)
 for lib in a.libs:
     v = res[lib]
