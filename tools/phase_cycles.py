@@ -31,7 +31,7 @@ assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(),
 torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
-names = ["passA+write", "barrier wait", "finalize+passB", "passC r/c", "passD in place", "bins+scatter+A", "loop tail", "-"]
+names = ["passA+write", "barrier wait", "finalize+passB", "passC r/c", "passD in place", "bins", "scatter+next A", "-"]
 if os.environ.get("EMSPEC_FUSED_VARIANT") == "pp":   # the half-iteration-apart variant stamps other phases (fused_pp.hip.inc)
     names = ["finalize", "passes B C D", "bins", "scatter", "next pass A", "team wait", "write+barrier", "-"]
 tot = cyc[:, :, :7].sum(axis=2).astype(np.float64)    # slot 7 is not a phase: rounds (low word) + 100 MHz ticks (high word)
@@ -40,7 +40,9 @@ for i, nm in enumerate(names[:7]):
     v = cyc[:, :, i].astype(np.float64)
     print(f"  {nm:16s} {100 * v.sum() / tot.sum():5.1f} %   per-iteration {v.mean() / ((Cn / (groups.value / S) + 16) / 2):8.0f}")
 it_ = (Cn / (groups.value / S) + 16) / 2
-print(f"accumulate rounds per wave per frame (4 calls): {(cyc[:, :, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64).mean() / it_:.2f}")
+rounds = (cyc[:, :, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64).mean() / it_
+if rounds > 0:      # only the variants that still count them (the default kernel's accumulate loop is assembly now)
+    print(f"accumulate rounds per wave per frame (4 calls): {rounds:.2f}")
 if len(sys.argv) > 2:
     print("per-wave mean cycles per iteration (rows: wave, cols: phases)")
     it = (Cn / (groups.value / S) + 16) / 2
