@@ -331,7 +331,7 @@ __device__ __forceinline__ void lds_accumulate(float* cell, float p, bool want) 
         "s_mov_b64 exec, %[sv]"
         : [old] "=&v"(old), [sv] "=&s"(sv), [tmp] "=&s"(tmp)
         : [addr] "v"(addr), [sent] "v"(0xFFFFFFFFu), [p] "v"(p), [wm] "s"(wmask)
-        : "vcc", "memory");
+        : "vcc", "scc", "memory");
 }
 // the same loop in C++ (what the assembly above does; kept as its specification)
 __device__ __forceinline__ void lds_accumulate_ref(float* cell, float p, bool want) {
