@@ -99,12 +99,17 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
         constexpr int B0 = LOG2N - S0 - 4;
         const int lo = t & ((1 << B0) - 1), hi = t >> B0;
         const int base = (hi << (B0 + 4)) + lo;
+        // padi(base + (i << B0)) = padi(base) + (i << B0) + pad_i with pad_i a compile-time constant: base = hi * 2^(B0+4)
+        // + lo with lo < 2^B0, so the 1-in-16 pad (p >> 4) of the sum splits exactly - the sixteen positions are ONE
+        // address register and immediate offsets instead of a shift and an add each
+        const int pb = padi(base);
+        auto poff = [](int i) constexpr { return (i << B0) + (B0 >= 4 ? (i << (B0 >= 4 ? B0 - 4 : 0)) : (i >> (B0 < 4 ? 4 - B0 : 0))); };
         float2 v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = sm[padi(base + (i << B0))];
+        for (int i = 0; i < 16; ++i) v[i] = sm[pb + poff(i)];
         fft_stages_w<4, TwLdsStrided, PRIO>(v, TwLdsStrided{stw + lo, 1 << B0});   // PRIO builds (fused N = 16384) are also the register-lean ones
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sm[padi(base + (i << B0))] = v[i];
+        for (int i = 0; i < 16; ++i) sm[pb + poff(i)] = v[i];
         wave_lds_sync();
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(3 - S0 / 4);   // S0 = 4 -> 2, S0 = 8 -> 1
         fft_rest<LOG2N, S0 + 4, INPLACE, PRIO>(sm, stw + (15 << B0), t, tw);
@@ -116,16 +121,15 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
         float2 v[G][1 << R];
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
-            const int g = G * t + gi;
 #pragma unroll
-            for (int i = 0; i < (1 << R); ++i) v[gi][i] = sm[padi((g << R) + i)];
+            for (int i = 0; i < (1 << R); ++i) v[gi][i] = sm[17 * t + (gi << R) + i];   // padi(16 t + m) = 17 t + m for m < 16
             fft_stages<LOG2N, S0, R>(v[gi], 0, tw);
         }
         if constexpr (INPLACE) {
 #pragma unroll
             for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int i = 0; i < (1 << R); ++i) sm[padi(((G * t + gi) << R) + i)] = v[gi][i];
+                for (int i = 0; i < (1 << R); ++i) sm[17 * t + (gi << R) + i] = v[gi][i];
             return;
         }
         __syncthreads();
@@ -174,7 +178,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     // stage "STFT": first pass (stages 0..3) straight from registers
     fft_stages<LOG2N, 0, 4>(v, t, pl.tw);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sm[padi(t + T * i)] = v[i];
+    for (int i = 0; i < 16; ++i) sm[padi(t) + (T + T / 16) * i] = v[i];   // padi(t + T i) = padi(t) + (T + T/16) i: T is a multiple of 16
     __syncthreads();
     fft_rest<LOG2N, 4>(sm, stw, t, pl.tw);
 
