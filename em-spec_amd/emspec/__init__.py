@@ -7,6 +7,7 @@ device is present, loading / Engine() raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -60,6 +61,15 @@ def load(diag=False):
     if diag in _libs:
         return _libs[diag]
     path = DIAG_LIB_PATH if diag else LIB_PATH
+    # PyTorch ships its own HIP runtime.  If libemspec.so (linked against /opt/rocm's) is loaded first, a later
+    # `import torch` brings a second runtime into the process and finds no device ("No HIP GPUs are available"); with
+    # torch first, libemspec's libamdhip64 dependency resolves to the copy already loaded.  The Python tooling (tests,
+    # bench, smoke) uses torch for device buffers, so settle the order here; hosts without torch are unaffected.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = C.CDLL(path)
