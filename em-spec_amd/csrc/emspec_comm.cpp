@@ -217,10 +217,11 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
             off[r + 1] = off[r] + (((size_t)c->h_sizes[2 * r] + 255) & ~(size_t)255);
             dst_off[r + 1] = dst_off[r] + (size_t)c->h_sizes[2 * r + 1] * R;
         }
-        if (dst_off[world] > (size_t)(gathered_capacity > 0 ? gathered_capacity : 0))
-            return fail(e, EMSPEC_ERR_INVALID_ARG, "the gathered buffer is smaller than the shards the ranks announced");
         if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc;
     }
+    // a gathered buffer that cannot hold the announced shards is the root's error alone: the transfers below still run
+    // (into the root's own receive buffer), so that the other ranks' sends complete, and only the expand is skipped
+    const bool fits = !is_root || dst_off[world] <= (size_t)(gathered_capacity > 0 ? gathered_capacity : 0);
     NCCLCHK(e, ncclGroupStart());
     ncclResult_t nr = ncclSuccess;
     if (i_send && c->h_sizes[2 * me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[2 * me], ncclUint8, root, c->comm, st);
@@ -230,6 +231,8 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     const ncclResult_t ge = ncclGroupEnd();
     if (nr != ncclSuccess) return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr));
     NCCLCHK(e, ge);
+
+    if (!fits) return fail(e, EMSPEC_ERR_INVALID_ARG, "the gathered buffer is smaller than the shards the ranks announced");
 
     // ---- root: expand every image into its rank's block of the gathered buffer (blocks in rank order, each as long as
     // that rank's shard); its own columns are a device copy
