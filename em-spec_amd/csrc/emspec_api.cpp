@@ -419,6 +419,23 @@ int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_
     return EMSPEC_OK;
 }
 
+int emspec_debug_recip(emspec_engine* e, const float* d, int64_t count, float* out_short, float* out_ieee) {
+    if (!e || !d || !out_short || !out_ieee || count < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    float *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    hipError_t r = hipMalloc(&d_in, count * 4 + 4);
+    if (r == hipSuccess) r = hipMalloc(&d_a, count * 4 + 4);
+    if (r == hipSuccess) r = hipMalloc(&d_b, count * 4 + 4);
+    if (r == hipSuccess) r = hipMemcpyAsync(d_in, d, count * 4, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = launch_recip_probe(d_in, count, d_a, d_b, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_short, d_a, count * 4, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_ieee, d_b, count * 4, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_in); (void)hipFree(d_a); (void)hipFree(d_b);
+    HIPCHK(e, r);
+    return EMSPEC_OK;
+}
+
 // Diagnostic (not part of the product path): run the stamped build of the fused kernel and
 // return, per workgroup and wave, the cycles spent in each barrier-delimited phase.
 // cycles: [groups][waves][8 slots] uint64 on the HOST; *groups receives the workgroup count and

@@ -221,6 +221,26 @@ struct HintLookup {
     __device__ __forceinline__ int operator()(float kh) const { return in_range(kh) ? row_unchecked(kh) : -1; }
 };
 
+// Upper power gate of stage "Power + gate" (DESIGN.md §3.4): bins above it are dropped.  1e36 keeps the reciprocal's
+// argument 64 P below 2^126, where 1/d is a normal number (a bin this strong needs |x| > 1e14 on input).
+constexpr float kPowerMax = 1.0e36f;
+// The specialised kernels use recip_normal below; their launcher requires this much power floor (64 P = d > 2^-90)
+constexpr float kFastMinFloor = 1.0e-27f;
+
+// 1/d, correctly rounded, for 2^-96 < d < 2^126: what hipcc's IEEE division (v_div_scale x2, v_rcp, 5 fma, v_div_fmas,
+// v_div_fixup: 11 instructions) computes when neither scaling nor a special case applies, without the four instructions
+// that only serve those cases.  The callers guarantee the range for every bin whose result is used: the power gate
+// keeps 64 P = d below 2^126 and the launcher selects these kernels only when the power floor keeps d above 2^-90.
+__device__ __forceinline__ float recip_normal(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    const float r1 = __builtin_fmaf(e, r, r);
+    const float rem = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(rem, r1, r1);
+    const float rem2 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(rem2, r1, q1);
+}
+
 struct BinOut { float power; int dcol; int row; };  // dcol relative to the frame's own column
 
 // (c + c) - s in one instruction: c + c is exact, so fma(2, c, -s) rounds the same real number once, like the
@@ -254,7 +274,7 @@ __device__ __forceinline__ BinOut reassign_core(const PlanDev& pl, const Lookup&
     o.power = den * 0.015625f;
     o.dcol = 0;
     o.row = -1;
-    if (o.power >= pl.pfloor_abs && o.power <= 3.0e38f) {
+    if (o.power >= pl.pfloor_abs && o.power <= kPowerMax) {
         if (pl.reassign) {
             float numT = __builtin_fmaf(Br, Ar, Bi * Ai);
             float numF = __builtin_fmaf(Dr, Ar, Di * Ai);

@@ -65,6 +65,7 @@ int fused_read_errflag();   // non-zero if a bounded spin of the decoupled-team 
 hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh, int64_t count, int32_t* out_hint,
                                    int32_t* out_exact, hipStream_t st);
 hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st);
+hipError_t launch_recip_probe(const float* d, int64_t count, float* out_short, float* out_ieee, hipStream_t st);
 #endif
 
 }  // namespace emspec

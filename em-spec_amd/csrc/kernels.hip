@@ -541,6 +541,19 @@ hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh,
     return hipGetLastError();
 }
 
+// Diagnostic: the short reciprocal beside the IEEE division (tests/test_gpu_parity.py sweeps whole binades)
+__global__ void recip_probe_kernel(const float* __restrict__ d, int64_t count, float* __restrict__ out_short,
+                                   float* __restrict__ out_ieee) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        out_short[i] = recip_normal(d[i]);
+        out_ieee[i] = 1.0f / d[i];
+    }
+}
+hipError_t launch_recip_probe(const float* d, int64_t count, float* out_short, float* out_ieee, hipStream_t st) {
+    hipLaunchKernelGGL(recip_probe_kernel, dim3(1024), dim3(256), 0, st, d, count, out_short, out_ieee);
+    return hipGetLastError();
+}
+
 // Diagnostic: hold `groups` workgroups of 256 threads on the device for about `usec` microseconds
 // (constant 100 MHz wall clock; the iteration cap bounds the spin whatever the clock does).  Stands in
 // for a communication kernel that occupies compute units beside the column kernels.

@@ -17,6 +17,10 @@ extern "C" {
 int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_t count,
                             int32_t* out_hint, int32_t* out_exact);
 
+/* Evaluate the kernels' 7-instruction reciprocal (recip_normal, emspec_device.h) and the IEEE division 1.0f / d on
+ * `count` host values: out_short[i], out_ieee[i].  They must agree bit for bit for 2^-96 < d < 2^126. */
+int emspec_debug_recip(emspec_engine* e, const float* d, int64_t count, float* out_short, float* out_ieee);
+
 /* Run the stamped build of the fused kernel on device-resident pcm and return, per
  * workgroup and wave, the shader-clock cycles spent in each barrier-delimited phase:
  * cycles[groups][waves][8] (host).  Call with cycles == NULL to get *groups / *waves. */

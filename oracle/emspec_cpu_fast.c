@@ -211,7 +211,7 @@ static void stream_fast(const fplan* p, const float* pcm, int64_t L, float* db, 
             float Ar = (Yr[k + 1] + Yr[k + 1]) - (Yr[k] + Yr[k + 2]), Ai = (Yi[k + 1] + Yi[k + 1]) - (Yi[k] + Yi[k + 2]);
             float den = Ar * Ar + Ai * Ai;
             float P = den * 0.015625f;
-            if (!(P >= p->pfloor_abs) || !(P <= 3.0e38f)) continue;
+            if (!(P >= p->pfloor_abs) || !(P <= 1.0e36f)) continue;
             float kh = (float)k;
             int col = sj;
             if (p->reassign) {

@@ -233,7 +233,7 @@ static void frame_f32(const plan32* p, const eo_cfg* c, const float* x, int64_t 
         float P = den * 0.015625f; /* |X_h|^2 = |A|^2 / 64, exact scaling */
         power[k] = P;
         int32_t cj = (int32_t)j, rw = -1;
-        if (P >= p->pfloor_abs && P <= 3.0e38f) {
+        if (P >= p->pfloor_abs && P <= 1.0e36f) {
             if (c->reassign) {
                 /* stage "Reassign": t-shift = Re(B conj A)/|A|^2 [units of N/2 samples],
                  *                   k-shift = Re(Dd conj A)/|A|^2 [bins]   */

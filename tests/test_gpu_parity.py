@@ -690,3 +690,35 @@ def test_bench_device_synth_matches_definition():
     got = bench.synth_device(2, 50000, 7, torch.device("cuda", 0)).cpu().numpy()
     ref = synth.streams(2, 50000, first=7)
     assert np.max(np.abs(got - ref)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_short_reciprocal_equals_ieee_division(diag_engine):
+    """The specialised kernels compute 1/den with recip_normal (7 instructions: v_rcp_f32 + six fma, emspec_device.h)
+    instead of hipcc's 11-instruction IEEE division.  Both are evaluated on the GPU for EVERY float of three binades
+    (2^23 mantissas each: scaling by a power of two is exact, so a binade stands for all of them away from the range's
+    ends), for the binades at both ends of the range the kernels guarantee (64 P between 2^-90 and 2^126: power floor
+    >= 1e-27 checked by the launcher, upper power gate 1e36), and for random values across it: bit-identical."""
+    import ctypes as C
+    import emspec
+    lib = emspec.load(diag=True)
+    lib.emspec_debug_recip.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+
+    def check(vals):
+        vals = np.ascontiguousarray(vals, np.float32)
+        a, b = np.empty_like(vals), np.empty_like(vals)
+        assert lib.emspec_debug_recip(diag_engine._h, vals.ctypes.data, vals.size, a.ctypes.data, b.ctypes.data) == 0
+        with np.errstate(all="ignore"):
+            ref = (np.float32(1.0) / vals).astype(np.float32)
+        assert np.array_equal(b.view(np.uint32), ref.view(np.uint32))          # the GPU's division is IEEE
+        bad = np.flatnonzero(a.view(np.uint32) != b.view(np.uint32))
+        assert bad.size == 0, (vals[bad[:5]], a[bad[:5]], b[bad[:5]])
+
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    for exp in (127, 127 + 20, 127 - 37, 127 - 90, 127 + 125):                   # biased exponents: 1, 2^20, 2^-37, 2^-90, 2^125
+        check(((np.uint32(exp) << np.uint32(23)) | mant).view(np.float32))
+    rng = np.random.default_rng(5)
+    bits = (rng.integers(127 - 90, 127 + 126, size=1 << 22).astype(np.uint32) << np.uint32(23)) | rng.integers(0, 1 << 23, size=1 << 22).astype(np.uint32)
+    check(bits.view(np.float32))
+    # the largest argument the power gate lets through: 64 * 1e36
+    check(np.array([64.0 * 1.0e36, np.nextafter(np.float32(64.0e36), np.float32(0))], np.float32))
