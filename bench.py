@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n8192", "n1024"])
+    ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n8192", "n1024", "paritydump"],
+                    help="paritydump: N=1 only, a step = the per-bin dump of 16 streams x 2^20 samples (the second roofline point of the default line, here on its own so that tools/profile_workload.sh can profile it)")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
     ap.add_argument("--log2-samples", type=int, default=22)
     ap.add_argument("--chunks", type=int, default=2, help="stream-chunks per step (gather overlap, N>1)")
@@ -269,6 +270,40 @@ def main():
     eng = emspec.Engine(device=dev_index)
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
+    if args.workload == "paritydump":
+        if world != 1:
+            sys.exit("paritydump is a one-GPU measurement")
+        import ctypes as C_
+        lib = emspec.load()
+        Sd, Ld = 16, 1 << 20
+        Cd, K = emspec.num_columns(Ld, n, hop), n // 2 + 1
+        sub = synth_device(Sd, Ld, 0, dev)
+        pw_ = torch.empty((Sd, Cd, K), dtype=torch.float32, device=dev)
+        cl_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+        rw_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+
+        def dump():
+            assert lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(), cl_.data_ptr(),
+                                                 rw_.data_ptr(), C_.c_void_p(cur.cuda_stream)) == 0
+        for _ in range(max(args.warmup, 1)):
+            dump()
+        torch.cuda.synchronize(dev)
+        ms = time_launches(dump, cur, args.steps)
+        bpc = 4 * hop + 12 * K
+        rf = roofline(Sd * Cd, bpc, ms, "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples")
+        pp, pf = profile_for("paritydump")
+        rf["traffic"] = pp.get("hbm_bytes_per_launch") if (pp and pf) else None
+        line = {"metric": "parity-dump columns/sec (4096-pt, hop 256, per-bin power + column + row)", "value": Sd * Cd / (ms * 1e-3),
+                "unit": "columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "per-bin parity dump, 16 streams x 2^20 samples, FFT 4096, hop 256, reassignment ON",
+                           "columns_per_step": Sd * Cd, "sources_sha": sources_sha()},
+                "roofline": rf, "cpu_baseline": None}
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
+        eng.close()
+        return
     total_streams = world * S
 
     # ---- gather set-up.  lib: libemspec's own communicator (RCCL), id handed over through torch.distributed.

@@ -157,8 +157,15 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     float2* stw = sm + PaddedSize<N>::value;                       // middle-pass twiddles
     float* seb = reinterpret_cast<float*>(stw + mid_tw_entries(LOG2N));
     const int t = threadIdx.x;
-    const int64_t f = blockIdx.x;          // frame within the launch
-    const int s = blockIdx.y;              // stream
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, so neighbouring frames - which
+    // share 15/16 of their samples - would land on different L2s and every L2 would fetch about half of every frame
+    // (PMC: 8.3 KB read per column against 1 KB algorithmic).  Re-deal them: XCD x takes the x-th eighth of the
+    // (stream, frame) sequence, a contiguous run, and the overlap is served by that XCD's L2.
+    const int64_t total = (int64_t)gridDim.x * gridDim.y, lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t full = total & ~(int64_t)7;
+    const int64_t work = lin < full ? (lin & 7) * (full >> 3) + (lin >> 3) : lin;
+    const int64_t f = work % gridDim.x;    // frame within the launch
+    const int s = (int)(work / gridDim.x); // stream
     const int64_t j = frame0 + f;          // frame within the pcm buffer
     const int64_t jcol = j + sk.col_offset; // its own absolute column
 

@@ -22,7 +22,23 @@ pcm = synth_device(S, L, 0, dev)
 db = torch.empty((S, C, eng.rows), dtype=torch.float32, device=dev)
 idx = torch.empty((S, C, eng.rows), dtype=torch.uint8, device=dev)
 cur = torch.cuda.current_stream(dev)
-ms = time_launches(lambda: eng.batch_device(pcm, n, hop, True, db=db, index=idx, stream=cur), cur, %(reps)d)
+if %(dump)d:
+    import ctypes as C_
+    lib = emspec.load()
+    Sd, Ld = 16, 1 << 20
+    Cd, K = emspec.num_columns(Ld, n, hop), n // 2 + 1
+    sub = pcm[:Sd, :Ld].contiguous()
+    pw_ = torch.empty((Sd, Cd, K), dtype=torch.float32, device=dev)
+    cl_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+    rw_ = torch.empty((Sd, Cd, K), dtype=torch.int32, device=dev)
+    def dump():
+        assert lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(), cl_.data_ptr(),
+                                             rw_.data_ptr(), C_.c_void_p(cur.cuda_stream)) == 0
+    eng.batch_device(pcm, n, hop, True, db=db, index=idx, stream=cur)     # warm the clock
+    ms = time_launches(dump, cur, 20)
+    idx.zero_(); db.zero_()
+else:
+    ms = time_launches(lambda: eng.batch_device(pcm, n, hop, True, db=db, index=idx, stream=cur), cur, %(reps)d)
 torch.cuda.synchronize()
 print(f"checksum idx {int(idx.sum(dtype=torch.int64).item())} db {float(db.double().sum().item()):.6e}", file=sys.stderr)
 print(f"{ms:.4f}")
@@ -34,6 +50,7 @@ ap.add_argument("--workload", default="batch64")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--n", type=int, default=0, help="FFT size (overrides --workload)")
 ap.add_argument("--hop", type=int, default=0)
+ap.add_argument("--dump", action="store_true", help="time the per-bin parity dump (16 streams x 2^20 samples) instead of the batch")
 a = ap.parse_args()
 n, hop, reps = (16384, 512, 4) if a.workload == "n16384" else (4096, 256, 8)
 if a.n:
@@ -41,7 +58,7 @@ if a.n:
 res = {l: [] for l in a.libs}
 for r in range(a.rounds):
     for lib in a.libs:
-        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps)],
+        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps, dump=int(a.dump))],
                              capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             sys.exit(out.stderr[-2000:])

@@ -5,6 +5,7 @@
 # separate PMC passes); 3. stamped-build phase cycles and the in-kernel clock; 4. gather cost; 5. host-API rates.
 # Afterwards, HERE:  python tools/profile_json.py gpurun_out/<tag>_batch64 <tag> batch64 1047616
 #                    python tools/profile_json.py gpurun_out/<tag>_n16384 <tag> n16384 522304
+#                    python tools/profile_json.py gpurun_out/<tag>_paritydump <tag> paritydump 65296
 #                    cp gpurun_out/<tag>_*.txt profiles/   and commit;
 # then a second call for the bench lines, which quote the counters only while profiles/<tag>_*.json match the kernels:
 #   gpurun -- 'python bench.py > gpurun_out/<tag>_bench_n1.json; python bench.py --gather loopback --no-cpu-baseline
@@ -20,6 +21,8 @@ bash tools/profile_workload.sh ${tag}_batch64 --no-configs > gpurun_out/prof_bat
 echo "batch64 profiled"
 bash tools/profile_workload.sh ${tag}_n16384 --workload n16384 > gpurun_out/prof_n16384.log 2>&1
 echo "n16384 profiled"
+bash tools/profile_workload.sh ${tag}_paritydump --workload paritydump --steps 20 > gpurun_out/prof_paritydump.log 2>&1
+echo "paritydump profiled"
 cd "$R"
 timeout -k 10 200 python tools/phase_cycles.py 64 waves > gpurun_out/${tag}_batch64_phase_cycles.txt 2>&1
 timeout -k 10 200 python tools/phase_cycles_n16384.py > gpurun_out/${tag}_n16384_phase_cycles.txt 2>&1 || true
