@@ -293,6 +293,32 @@ __device__ __forceinline__ BinOut reassign_core(const PlanDev& pl, const Lookup&
     return o;
 }
 
+// The same stages without a branch, for a plan the caller knows to be "fast" (reassignment ON, log-spaced rows, power
+// floor >= kFastMinFloor: emspec_plan_is_fast): everything is computed, the gates select at the end.  Same results as
+// reassign_core, bit for bit (recip_normal == 1.0f / den on the gated range; row_signed_log walks off the table exactly
+// when k-hat is out of range).
+__device__ __forceinline__ BinOut reassign_core_fast(const PlanDev& pl, const HintLookup& lk, int k,
+                                                     const YT& m, const YT& c, const YT& p) {
+    const float Ar = (c.yr + c.yr) - (m.yr + p.yr), Ai = (c.yi + c.yi) - (m.yi + p.yi);
+    const float Br = (c.tr + c.tr) - (m.tr + p.tr), Bi = (c.ti + c.ti) - (m.ti + p.ti);
+    const float Dr = m.yr - p.yr, Di = m.yi - p.yi;
+    const float den = __builtin_fmaf(Ar, Ar, Ai * Ai);
+    BinOut o;
+    o.power = den * 0.015625f;
+    const float numT = __builtin_fmaf(Br, Ar, Bi * Ai);
+    const float numF = __builtin_fmaf(Dr, Ar, Di * Ai);
+    const float inv = recip_normal(den);
+    const float cf = __builtin_floorf(__builtin_fmaf(numT * inv, pl.tscale, 0.5f));
+    const bool ok = (o.power >= pl.pfloor_abs) && (o.power <= kPowerMax) && (__builtin_fabsf(cf) <= (float)pl.D);
+    const int rr = lk.row_signed_log((float)k + numF * inv);
+    o.dcol = ok ? (int)cf : 0;
+    o.row = (ok && (unsigned)rr < (unsigned)lk.R) ? rr : -1;
+    return o;
+}
+__device__ __host__ __forceinline__ bool emspec_plan_is_fast(const PlanDev& pl) {
+    return pl.reassign && pl.log_rows && pl.pfloor_abs >= kFastMinFloor;
+}
+
 //   zm,z0,zp = Z[k-1],Z[k],Z[k+1] ;  wm,w0,wp = Z[N-k+1],Z[N-k],Z[N-k-1]
 __device__ __forceinline__ BinOut reassign_bin(const PlanDev& pl, const float* eb, int wtop, int k,
                                                float2 zm, float2 z0, float2 zp,

@@ -147,7 +147,12 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
     }
 }
 
-template <int LOG2N>
+// SINK: which outputs are compiled in.  0 = whatever the FrameSinks say at run time (the streaming call: histogram
+// atomics + the finished column); 1 = the parity dump only; 2 = the records for the tile scatter only.  With the
+// run-time form every bin re-tests five sink pointers and recomputes three 64-bit frame offsets on the scalar unit -
+// a few hundred instructions of each wave's stream per frame.
+// FASTC: the plan is "fast" (emspec_plan_is_fast): the branch-free per-bin core.
+template <int LOG2N, int SINK, bool FASTC = false>
 __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     PlanDev pl, const float* __restrict__ pcm, int64_t L, int64_t frame0, int64_t nframes,
     FrameSinks sk) {
@@ -192,6 +197,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
     HintLookup lk;
     lk.init(seb, pl.ebin, pl.rows, pl.log_rows);
+    const size_t fidx = (size_t)s * nframes + f;                   // this frame's index in the per-frame output arrays
+    float* const out_power = (SINK == 1 || (SINK == 0 && sk.power)) ? sk.power + fidx * K : nullptr;
+    int32_t* const out_col = out_power ? sk.col + fidx * K : nullptr;
+    int32_t* const out_row = out_power ? sk.row + fidx * K : nullptr;
+    uint2* const out_rec = (SINK == 2 || (SINK == 0 && sk.records)) ? sk.records + fidx * (K + 1) : nullptr;
 #pragma unroll EMSPEC_BINS_UNROLL
     for (int i = 0; i < 9; ++i) {
         const int k = t + T * i;
@@ -199,26 +209,28 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         const float2 zm = sm[natpos<LOG2N>((k - 1) & (N - 1))], z0 = sm[natpos<LOG2N>(k)], zp = sm[natpos<LOG2N>(k + 1)];
         const float2 wm = sm[natpos<LOG2N>((N - k + 1) & (N - 1))], w0 = sm[natpos<LOG2N>((N - k) & (N - 1))],
                      wp = sm[natpos<LOG2N>(N - k - 1)];
-        const BinOut o = reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
+        const BinOut o = FASTC ? reassign_core_fast(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp))
+                               : reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
         const int64_t col = jcol + o.dcol;
-        if (sk.power) {
-            const size_t idx = ((size_t)s * nframes + f) * K + k;
-            sk.power[idx] = o.power;
-            sk.col[idx] = (int32_t)col;
-            sk.row[idx] = o.row;
+        if (SINK == 1 || (SINK == 0 && out_power)) {
+            out_power[k] = o.power;
+            out_col[k] = (int32_t)col;
+            out_row[k] = o.row;
         }
-        if (sk.records) {
+        if (SINK == 2 || (SINK == 0 && out_rec)) {
             // frame stride is K+1 (even): 16-byte aligned chunks; the pad record is marked dropped
-            const size_t idx = ((size_t)s * nframes + f) * (K + 1) + k;
             const unsigned key = o.row >= 0 ? ((unsigned)(o.dcol + 32768) << 16) | (unsigned)o.row : 0xFFFFFFFFu;
-            sk.records[idx] = make_uint2(__float_as_uint(o.power), key);
-            if (k == N / 2) sk.records[idx + 1] = make_uint2(0u, 0xFFFFFFFFu);
+            out_rec[k] = make_uint2(__float_as_uint(o.power), key);
+            if (k == N / 2) out_rec[k + 1] = make_uint2(0u, 0xFFFFFFFFu);
         }
-        if (sk.hist && o.row >= 0 && col >= 0 && col < sk.total_cols) {
-            const int64_t slot = sk.ring ? (col % sk.hist_slots) : col;
-            atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
+        if constexpr (SINK == 0) {
+            if (sk.hist && o.row >= 0 && col >= 0 && col < sk.total_cols) {
+                const int64_t slot = sk.ring ? (col % sk.hist_slots) : col;
+                atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
+            }
         }
     }
+    if constexpr (SINK != 0) return;
     if (sk.fin_db || sk.fin_rgba) {
         // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
         // frame's atomics are ordered by the fence + barrier, so column fin_col is complete: emit it and clear its
@@ -245,15 +257,26 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     constexpr int N = 1 << LOG2N;
     const size_t lds = (size_t)(PaddedSize<N>::value + mid_tw_entries(LOG2N)) * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // the sink combination picks the build: dump only, records only, or the run-time form
+    const bool plain = !sk.hist && !sk.fin_db && !sk.fin_rgba;
+    const int sink = (plain && sk.power && !sk.records) ? 1 : ((plain && sk.records && !sk.power) ? 2 : 0);
+    const bool fastc = sink != 0 && emspec_plan_is_fast(pl);
+    const void* fn = sink == 1 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1>))
+                   : sink == 2 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2>))
+                               : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 0>);
     if (lds > 64 * 1024) {
-        const hipError_t e = allow_max_lds(reinterpret_cast<const void*>(&frames_kernel<LOG2N>));
+        const hipError_t e = allow_max_lds(fn);
         if (e != hipSuccess) return e;
     }
     // grid.x is limited to 2^31-1, grid.y to 65535
     if (nframes <= 0 || S <= 0) return hipSuccess;
     if (S > 65535 || nframes > 0x7fffffffLL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nframes, (unsigned)S), block(N / 16);
-    hipLaunchKernelGGL(frames_kernel<LOG2N>, grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    if (sink == 1 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 1, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else if (sink == 1) hipLaunchKernelGGL((frames_kernel<LOG2N, 1>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else if (sink == 2 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 2, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else if (sink == 2) hipLaunchKernelGGL((frames_kernel<LOG2N, 2>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else hipLaunchKernelGGL((frames_kernel<LOG2N, 0>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     return hipGetLastError();
 }
 
