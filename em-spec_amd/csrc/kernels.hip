@@ -135,12 +135,15 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
         __syncthreads();
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
+            // bitrev(g 2^R + i) = bitrev_R(i) 2^(LOG2N-R) + bitrev_(LOG2N-R)(g), and natpos swizzles with bits below
+            // LOG2N-R only: one swizzled base per group, the 2^R slots at compile-time offsets
             const int g = G * t + gi;
+            const int kb = natpos<LOG2N>((int)(__brev((unsigned)g) >> (32 - (LOG2N - R))));
 #pragma unroll
             for (int i = 0; i < (1 << R); ++i) {
-                const unsigned p = (unsigned)((g << R) + i);
-                const unsigned k = __brev(p) >> (32 - LOG2N);
-                sm[natpos<LOG2N>((int)k)] = v[gi][i];
+                constexpr int SH = LOG2N - R;
+                const int bi = ((i & 1) << 3 | (i & 2) << 1 | (i & 4) >> 1 | (i & 8) >> 3) >> (4 - R);   // bitrev_R(i)
+                sm[kb + (bi << SH)] = v[gi][i];
             }
         }
         __syncthreads();
@@ -153,7 +156,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 // a few hundred instructions of each wave's stream per frame.
 // FASTC: the plan is "fast" (emspec_plan_is_fast): the branch-free per-bin core.
 template <int LOG2N, int SINK, bool FASTC = false>
-__global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
+__global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N <= 12 && SINK != 0) ? 4 : 1) void frames_kernel(
     PlanDev pl, const float* __restrict__ pcm, int64_t L, int64_t frame0, int64_t nframes,
     FrameSinks sk) {
     constexpr int N = 1 << LOG2N, T = N / 16, K = N / 2 + 1;
@@ -202,13 +205,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     int32_t* const out_col = out_power ? sk.col + fidx * K : nullptr;
     int32_t* const out_row = out_power ? sk.row + fidx * K : nullptr;
     uint2* const out_rec = (SINK == 2 || (SINK == 0 && sk.records)) ? sk.records + fidx * (K + 1) : nullptr;
-#pragma unroll EMSPEC_BINS_UNROLL
-    for (int i = 0; i < 9; ++i) {
-        const int k = t + T * i;
-        if (k > N / 2) break;
-        const float2 zm = sm[natpos<LOG2N>((k - 1) & (N - 1))], z0 = sm[natpos<LOG2N>(k)], zp = sm[natpos<LOG2N>(k + 1)];
-        const float2 wm = sm[natpos<LOG2N>((N - k + 1) & (N - 1))], w0 = sm[natpos<LOG2N>((N - k) & (N - 1))],
-                     wp = sm[natpos<LOG2N>(N - k - 1)];
+    auto do_bin = [&](int k, int pzm, int pz0, int pzp, int pwm, int pw0, int pwp) {
+        const float2 zm = sm[pzm], z0 = sm[pz0], zp = sm[pzp];
+        const float2 wm = sm[pwm], w0 = sm[pw0], wp = sm[pwp];
         const BinOut o = FASTC ? reassign_core_fast(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp))
                                : reassign_core(pl, lk, k, split_yt(zm, wm), split_yt(z0, w0), split_yt(zp, wp));
         const int64_t col = jcol + o.dcol;
@@ -229,7 +228,27 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
                 atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
             }
         }
+    };
+    auto do_bin_general = [&](int k) {
+        do_bin(k, natpos<LOG2N>((k - 1) & (N - 1)), natpos<LOG2N>(k), natpos<LOG2N>(k + 1), natpos<LOG2N>((N - k + 1) & (N - 1)),
+               natpos<LOG2N>((N - k) & (N - 1)), natpos<LOG2N>(N - k - 1));
+    };
+    do_bin_general(t);                                             // i = 0: the neighbours of bin 0 wrap round
+    {
+        // i = 1 .. 7: k = t + T i.  The swizzle of natpos reads bits below log2(T) only, so natpos(a + T m) = natpos(a)
+        // + T m for a < T: each of the six spectrum positions is a per-thread base plus (or minus) T i - six adds per bin
+        // instead of six swizzles (the mirrored positions count down).
+        const int bzm = natpos<LOG2N>((t - 1) & (T - 1)) - (t == 0 ? T : 0);
+        const int bz0 = natpos<LOG2N>(t);
+        const int bzp = natpos<LOG2N>((t + 1) & (T - 1)) + (t == T - 1 ? T : 0);
+        const int bwm = natpos<LOG2N>((1 - t) & (T - 1)) + T * (16 - (t >= 2 ? 1 : 0));
+        const int bw0 = natpos<LOG2N>((0 - t) & (T - 1)) + T * (16 - (t >= 1 ? 1 : 0));
+        const int bwp = natpos<LOG2N>(T - 1 - t) + T * 15;
+#pragma unroll EMSPEC_BINS_UNROLL
+        for (int i = 1; i < 8; ++i)
+            do_bin(t + T * i, bzm + T * i, bz0 + T * i, bzp + T * i, bwm - T * i, bw0 - T * i, bwp - T * i);
     }
+    if (t == 0) do_bin_general(N / 2);                             // the Nyquist bin
     if constexpr (SINK != 0) return;
     if (sk.fin_db || sk.fin_rgba) {
         // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
