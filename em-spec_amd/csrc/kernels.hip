@@ -156,7 +156,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 // a few hundred instructions of each wave's stream per frame.
 // FASTC: the plan is "fast" (emspec_plan_is_fast): the branch-free per-bin core.
 template <int LOG2N, int SINK, bool FASTC = false>
-__global__ __launch_bounds__((1 << LOG2N) / 16, (LOG2N <= 12 && SINK != 0) ? 4 : 1) void frames_kernel(
+__global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     PlanDev pl, const float* __restrict__ pcm, int64_t L, int64_t frame0, int64_t nframes,
     FrameSinks sk) {
     constexpr int N = 1 << LOG2N, T = N / 16, K = N / 2 + 1;
