@@ -681,6 +681,34 @@ def test_bench_two_rank_rehearsal():
     assert b["value"] > 0 and b["cpu_baseline"] is None
 
 
+def test_bench_two_rank_uneven_split_rehearsal():
+    """The N > 1 stream split (the collecting rank takes a lighter shard; bench.py tries five splits and keeps the fastest)
+    rehearsed with two ranks on this one GPU over gloo: the trial loop, the re-built buffers and the uneven point-to-point
+    gather are the code the 8-GPU run executes; only the transport differs (libemspec's RCCL gather needs one GPU per rank)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+            "--streams", "32", "--log2-samples", "17", "--chunks", "2", "--backend", "gloo"]
+    C = (2 ** 17 - 4096) // 256 + 1
+    for extra, check in (([], "trials"), (["--root-streams", "20"], "pinned")):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        b = json.loads(lines[0])
+        counts = b["config"]["streams_per_rank"]
+        assert sum(counts) == 64 and b["config"]["columns_per_step"] == 64 * C and b["value"] > 0
+        if check == "trials":
+            trials = b["gather"]["split_trials"]
+            assert len(trials) == 5 and all(sum(t["streams_per_rank"]) == 64 and t["columns_per_s"] > 0 for t in trials)
+            assert counts in [t["streams_per_rank"] for t in trials]
+            assert counts == max(trials, key=lambda t: t["columns_per_s"])["streams_per_rank"]
+        else:
+            assert counts == [20, 44] and b["gather"]["split_trials"] is None
+
+
 def test_bench_device_synth_matches_definition():
     """bench.py generates its input on the device from the same counter-based definition as emspec/synth.py."""
     import os, sys
