@@ -330,6 +330,9 @@ def main():
 
     def barrier():
         if world > 1:
+            # drain this rank's work first: libemspec's communicator and torch's are two RCCL communicators in one process,
+            # and their kernels should not wait on peers at the same time
+            torch.cuda.synchronize(dev)
             dist.barrier()
         torch.cuda.synchronize(dev)
 
