@@ -226,9 +226,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the side measurements of the other named configs")
     ap.add_argument("--force-chunks", type=int, default=0, help="N=1: launch per stream-chunk as the N>1 path does (no gather)")
     ap.add_argument("--reassign", type=int, default=1)
-    ap.add_argument("--gather", default="lib", choices=["lib", "torch", "loopback"],
+    ap.add_argument("--gather", default="lib", choices=["lib", "torch", "loopback", "dist-loopback"],
                     help="lib = libemspec's RCCL gather (default); torch = torch.distributed.gather of raw columns; "
-                         "loopback = N=1 rehearsal: the rank's own columns go through pack + RCCL self send/recv + expand")
+                         "loopback = N=1 rehearsal: the rank's own columns go through pack + RCCL self send/recv + expand; "
+                         "dist-loopback = the same with torch.distributed's NCCL group alive as at N>1 (id broadcast, barriers "
+                         "and reductions through it, two RCCL communicators in the process)")
     ap.add_argument("--root-streams", type=int, default=-1,
                     help="N>1: streams on rank 0, which also expands the gathered columns (default: try a few splits, keep the fastest)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -242,11 +244,17 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
-    if world > 1:
+    dist_on = world > 1 or args.gather == "dist-loopback"     # torch.distributed initialised (N>1, or the one-rank rehearsal of it)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29537")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    if dist_on:
         torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -308,7 +316,7 @@ def main():
 
     # ---- gather set-up.  lib: libemspec's own communicator (RCCL), id handed over through torch.distributed.
     gather_mode, gather_note = "none", None
-    if world > 1:
+    if dist_on:
         gather_mode = "torch" if (args.gather == "torch" or args.backend == "gloo") else "lib"
         if gather_mode == "lib":
             try:
@@ -329,7 +337,7 @@ def main():
     nbuf = 2 if gathering else 1       # N>1: two index buffers, so the gather of step k's last chunk overlaps step k+1's first kernels
 
     def barrier():
-        if world > 1:
+        if dist_on:
             # drain this rank's work first: libemspec's communicator and torch's are two RCCL communicators in one process,
             # and their kernels should not wait on peers at the same time
             torch.cuda.synchronize(dev)
@@ -421,13 +429,13 @@ def main():
             self.flush()
             barrier()
             el = time.perf_counter() - t0
-            if world > 1:
+            if dist_on:
                 tmax = torch.tensor([el], dtype=torch.float64, device=gdev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 el = float(tmax.item())
             return el
 
-    if world > 1 and gather_mode == "torch":
+    if dist_on and gather_mode == "torch":
         # open the point-to-point connections the gather uses before anything is timed
         probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
         shard.gather_columns_into(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
@@ -464,7 +472,7 @@ def main():
     job.flush()
     elapsed = job.run(args.steps, timed=True)
     wire_bytes = job.wire_bytes
-    if world > 1:
+    if dist_on:
         wb = torch.tensor(wire_bytes, dtype=torch.float64, device=gdev)
         dist.all_reduce(wb, op=dist.ReduceOp.SUM)
         wire_bytes = [float(wb[0].item()), float(wb[1].item())]
@@ -595,7 +603,7 @@ def main():
             line["cpu_baseline"] = None
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

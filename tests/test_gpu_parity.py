@@ -709,6 +709,25 @@ def test_bench_two_rank_uneven_split_rehearsal():
             assert counts == [20, 44] and b["gather"]["split_trials"] is None
 
 
+def test_bench_one_rank_with_process_group_rehearsal():
+    """bench.py --gather dist-loopback: ONE rank, but everything the N > 1 run does around the gather is alive -
+    torch.distributed's NCCL process group (the id broadcast, barriers and reductions go through it), libemspec's own
+    RCCL communicator beside it in the same process, the chunked pipeline with the host synchronisation inside the
+    gather - and the rank's own columns take the wire (pack, self send/recv, expand)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29539")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gather", "dist-loopback", "--no-cpu-baseline", "--no-configs",
+           "--steps", "3", "--warmup", "1", "--streams", "8", "--log2-samples", "19"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 1 and b["gather"]["path"] == "lib" and b["gather"]["note"] is None
+    assert 32 < b["gather"]["wire_bytes_per_column"] < 768 and b["value"] > 0
+
+
 def test_bench_device_synth_matches_definition():
     """bench.py generates its input on the device from the same counter-based definition as emspec/synth.py."""
     import os, sys
