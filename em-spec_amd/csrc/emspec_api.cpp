@@ -54,6 +54,35 @@ void default_lut(uint8_t* lut) {
     }
 }
 
+// (oracle/emspec_exact.c:ex_cos_sin states the same operations)
+/* cos and sin of a in [0, pi/4] by their Taylor series in Horner form, plain binary64 operations in this order (no
+ * libm call: glibc's sincos(), which gcc substitutes for a cos()/sin() pair, and its separate cos()/sin() differ in the
+ * last bit for some arguments, so a table built from libm depends on the compiler).  Truncation < 3e-18; result
+ * within about one ulp. */
+void cos_sin_octant(double a, double* c, double* s) {
+    const double z = a * a;
+    double ps = -1.0 / 121645100408832000.0;       /* -1/19! */
+    ps = ps * z + 1.0 / 355687428096000.0;         /* +1/17! */
+    ps = ps * z - 1.0 / 1307674368000.0;           /* -1/15! */
+    ps = ps * z + 1.0 / 6227020800.0;              /* +1/13! */
+    ps = ps * z - 1.0 / 39916800.0;                /* -1/11! */
+    ps = ps * z + 1.0 / 362880.0;                  /* +1/9! */
+    ps = ps * z - 1.0 / 5040.0;                    /* -1/7! */
+    ps = ps * z + 1.0 / 120.0;                     /* +1/5! */
+    ps = ps * z - 1.0 / 6.0;                       /* -1/3! */
+    *s = a + a * (ps * z);
+    double pc = 1.0 / 6402373705728000.0;          /* +1/18! */
+    pc = pc * z - 1.0 / 20922789888000.0;          /* -1/16! */
+    pc = pc * z + 1.0 / 87178291200.0;             /* +1/14! */
+    pc = pc * z - 1.0 / 479001600.0;               /* -1/12! */
+    pc = pc * z + 1.0 / 3628800.0;                 /* +1/10! */
+    pc = pc * z - 1.0 / 40320.0;                   /* -1/8! */
+    pc = pc * z + 1.0 / 720.0;                     /* +1/6! */
+    pc = pc * z - 1.0 / 24.0;                      /* -1/4! */
+    pc = pc * z + 0.5;                             /* +1/2! */
+    *c = 1.0 - pc * z;
+}
+
 int latency(int n, int hop, int reassign) { return reassign ? (n + 2 * hop - 1) / (2 * hop) : 0; }
 
 int check_shape(const emspec_engine* e, int n, int hop) {
@@ -98,6 +127,36 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
     HIPCHK(e, hipMalloc(&p.d_ebin, sizeof(float) * (R + 1)));
     HIPCHK(e, hipMemcpy(p.d_tw, p.h_tw.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(p.d_ebin, p.h_ebin.data(), sizeof(float) * (R + 1), hipMemcpyHostToDevice));
+    if (e->exact()) {
+        // the same tables in binary64 (oracle/emspec_exact.c: ex_twiddle, eo_edges64)
+        std::vector<double> tw((size_t)n), eb((size_t)R + 1);
+        for (int q = 0; q <= n / 8; ++q) {   // first octant by the specified series, second by cos(pi/2 - x) = sin x
+            double c, sn;
+            cos_sin_octant(2.0 * pi * (double)q / (double)n, &c, &sn);
+            tw[2 * q] = c;
+            tw[2 * q + 1] = -sn;
+            if (q > 0) {
+                tw[2 * (n / 4 - q)] = sn;
+                tw[2 * (n / 4 - q) + 1] = -c;
+            }
+        }
+        for (int q = 0; q < n / 4; ++q) {
+            tw[2 * (q + n / 4)] = tw[2 * q + 1];
+            tw[2 * (q + n / 4) + 1] = -tw[2 * q];
+        }
+        tw[2 * (n / 4)] = 0.0;
+        tw[2 * (n / 4) + 1] = -1.0;
+        for (int r = 0; r <= R; ++r)
+            eb[r] = e->custom_edges_hz.empty()
+                        ? (double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n / (double)e->cfg.sample_rate
+                        : (double)e->custom_edges_hz[r] * (double)n / (double)e->cfg.sample_rate;
+        for (int r = 0; r < R; ++r)
+            if (!(eb[r] < eb[r + 1])) return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges are not strictly increasing");
+        HIPCHK(e, hipMalloc(&p.d_tw64, sizeof(double) * n));
+        HIPCHK(e, hipMalloc(&p.d_ebin64, sizeof(double) * (R + 1)));
+        HIPCHK(e, hipMemcpy(p.d_tw64, tw.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(p.d_ebin64, eb.data(), sizeof(double) * (R + 1), hipMemcpyHostToDevice));
+    }
     auto ins = e->plans.emplace(n, std::move(p));
     *out = &ins.first->second;
     return EMSPEC_OK;
@@ -117,6 +176,36 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     d.pfloor_abs = (float)((double)e->cfg.power_floor * pk * pk);
     d.shared = comm_shares_device(e) ? 1 : 0;
     return d;
+}
+
+// EXACT mode: the plan and the dB map in binary64 (oracle/emspec_exact.c: explan_init, eo_batch_exact)
+ExactPlanDev exact_plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
+    ExactPlanDev d;
+    d.tw = p.d_tw64;
+    d.ebin = p.d_ebin64;
+    d.rows = e->cfg.rows;
+    d.log_rows = e->custom_edges_hz.empty() ? 1 : 0;
+    d.D = latency(p.n, hop, reassign);
+    d.reassign = reassign ? 1 : 0;
+    d.hop = hop;
+    d.tscale = (double)p.n / 2.0 / (double)hop;
+    const double pk = (double)p.n / 4.0;
+    d.pfloor = (double)e->cfg.power_floor * pk * pk;
+    int log2n = 0;
+    while ((1 << log2n) < p.n) ++log2n;
+    d.qscale = std::ldexp(1.0, 52 - (2 * log2n - 4));
+    d.pmax = std::ldexp(1.0, 61) / d.qscale;
+    return d;
+}
+ExactDbMap exact_db_map(const emspec_engine* e, int n, const ExactPlanDev& pd) {
+    ExactDbMap m;
+    const double nn = (double)n;
+    m.scale = 32.0 / (3.0 * nn * nn) * (double)e->cfg.gain * (double)e->cfg.gain;
+    m.lo = (double)e->cfg.db_top - (double)e->cfg.db_range;
+    m.inv_range = 1.0 / (double)e->cfg.db_range;
+    m.gate = (double)e->cfg.gate_db;
+    m.inv_q = 1.0 / pd.qscale;
+    return m;
 }
 
 DbMap db_map(const emspec_engine* e, int n) {
@@ -157,6 +246,7 @@ int emspec_create(const emspec_config* cfg, emspec_engine** out) {
     *out = nullptr;
     if (cfg->abi_version != EMSPEC_ABI_VERSION) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "abi_version mismatch");
     if (cfg->rows < 64 || cfg->rows > 4096 || cfg->rows % 4) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "rows must be a multiple of 4 in [64,4096]");
+    if (cfg->mode != EMSPEC_MODE_FAST && cfg->mode != EMSPEC_MODE_EXACT) return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "mode must be EMSPEC_MODE_FAST or EMSPEC_MODE_EXACT");
     if (!(cfg->sample_rate > 0) || !(cfg->fmin_hz > 0) || !(cfg->fmax_hz > cfg->fmin_hz) || !(cfg->db_range > 0) ||
         !(cfg->gain > 0) || !(cfg->power_floor >= 0))
         return fail(nullptr, EMSPEC_ERR_INVALID_ARG, "bad sample_rate/fmin/fmax/db_range/gain/power_floor");
@@ -211,11 +301,14 @@ void emspec_destroy(emspec_engine* e) {
 const char* emspec_last_error(const emspec_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign) {
-    return e && fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
+    return e && !e->exact() && fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
 }
 
 static void drop_plans(emspec_engine* e) {
-    for (auto& kv : e->plans) { (void)hipFree(kv.second.d_tw); (void)hipFree(kv.second.d_ebin); }
+    for (auto& kv : e->plans) {
+        (void)hipFree(kv.second.d_tw); (void)hipFree(kv.second.d_ebin);
+        (void)hipFree(kv.second.d_tw64); (void)hipFree(kv.second.d_ebin64);
+    }
     e->plans.clear();
 }
 
@@ -345,6 +438,33 @@ static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, cons
     return EMSPEC_OK;
 }
 
+// EXACT mode: per-bin (q, key) records (exact_frames_kernel) -> u64 LDS tiles (exact_tile_scatter_kernel), in chunks of
+// streams so the record workspace stays bounded
+static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                             int32_t reassign, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st) {
+    int rc;
+    const ExactPlanDev pd = exact_plan_dev(e, p, hop, reassign);
+    const ExactDbMap m = exact_db_map(e, n, pd);
+    const size_t Kp = (size_t)exact_record_stride(n);
+    const size_t q_per_stream = (size_t)C * Kp * sizeof(long long), key_per_stream = (size_t)C * Kp * sizeof(uint32_t);
+    const size_t budget = (size_t)12 << 30;
+    int chunk = (int)(budget / (q_per_stream + key_per_stream));
+    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
+    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, (q_per_stream + key_per_stream) * chunk + 256))) return rc;
+    const size_t col_cells = (size_t)C * e->cfg.rows;
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int sc = (S - s0 < chunk) ? S - s0 : chunk;
+        ExactSinks sk;
+        sk.rec_q = reinterpret_cast<long long*>(e->d_hist);
+        sk.rec_key = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(e->d_hist) + ((q_per_stream * chunk + 255) & ~(size_t)255));
+        HIPCHK(e, launch_exact_frames(n, pd, pcm + (size_t)s0 * L, L, sc, 0, C, sk, st));
+        HIPCHK(e, launch_exact_tile_scatter(sk.rec_q, sk.rec_key, n, pd, m, e->d_lut, sc, C, db ? db + s0 * col_cells : nullptr,
+                                            rgba ? rgba + 4 * s0 * col_cells : nullptr,
+                                            index ? index + s0 * col_cells : nullptr, st));
+    }
+    return EMSPEC_OK;
+}
+
 extern "C" {
 
 int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
@@ -368,11 +488,13 @@ int emspec_batch_device(emspec_engine* e, const float* pcm, int32_t S, int64_t L
         if ((rc = grow(e, (void**)&e->d_peak, &e->peak_bytes, (size_t)S * C * 8 + 16))) return rc;
         float* outdb = db;
         if (!outdb) { if ((rc = grow(e, (void**)&e->d_post, &e->post_bytes, cells * 4))) return rc; outdb = e->d_post; }
-        if ((rc = run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, e->d_raw, nullptr, nullptr, st))) return rc;
+        if ((rc = e->exact() ? run_columns_exact(e, *p, pcm, S, L, n, hop, reassign, C, e->d_raw, nullptr, nullptr, st)
+                             : run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, e->d_raw, nullptr, nullptr, st))) return rc;
         HIPCHK(e, launch_postprocess(e->d_raw, outdb, rgba, index, S, C, e->cfg.rows, e->smoothing, e->agc,
                                      e->cfg.db_top, m, e->d_lut, e->d_peak, e->d_peak + (size_t)S * C, st));
         return EMSPEC_OK;
     }
+    if (e->exact()) return run_columns_exact(e, *p, pcm, S, L, n, hop, reassign, C, db, rgba, index, st);
     return run_columns(e, pd, m, pcm, S, L, n, hop, reassign, C, db, rgba, index, st);
 }
 
@@ -538,6 +660,7 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm, int32_t S, int
                               int32_t reassign, int64_t frame0, int64_t nframes, float* power, int32_t* col,
                               int32_t* row, void* hip_stream) {
     if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    if (e->exact()) return fail(e, EMSPEC_ERR_STATE, "engine is in EXACT mode: use emspec_parity_dump_exact");
     int rc = check_shape(e, n, hop);
     if (rc) return rc;
     const int64_t C = emspec_num_columns(L, n, hop);
@@ -557,6 +680,7 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm, int32_t S, int
 int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
                        int32_t reassign, int64_t frame0, int64_t nframes, float* power, int32_t* col, int32_t* row) {
     if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    if (e->exact()) return fail(e, EMSPEC_ERR_STATE, "engine is in EXACT mode: use emspec_parity_dump_exact");
     int rc = check_shape(e, n, hop);
     if (rc) return rc;
     if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
@@ -577,6 +701,41 @@ int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
     HIPCHK(e, hipMemcpyAsync(power, d_pw, nb * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(col, d_col, nb * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(row, d_row, nb * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return EMSPEC_OK;
+}
+
+int emspec_parity_dump_exact(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
+                             int32_t reassign, int64_t frame0, int64_t nframes, double* power, int32_t* col, int32_t* row,
+                             int64_t* q) {
+    if (!e || !pcm || !power || !col || !row) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    if (!e->exact()) return fail(e, EMSPEC_ERR_STATE, "engine is in FAST mode: use emspec_parity_dump");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || S > 65535 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need 1..65535 streams of at least fft-size samples");
+    if (frame0 < 0 || nframes < 0 || frame0 + nframes > emspec_num_columns(L, n, hop))
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "frame range outside the stream");
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* p;
+    if ((rc = get_plan(e, n, &p))) return rc;
+    const ExactPlanDev pd = exact_plan_dev(e, *p, hop, reassign);
+    const size_t nb = (size_t)S * nframes * (n / 2 + 1);
+    const size_t b_pcm = (size_t)S * L * sizeof(float);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, al(b_pcm) + 2 * al(nb * 8) + 2 * al(nb * 4) + 256))) return rc;
+    char* base = e->d_stage;
+    float* d_pcm = (float*)base; base += al(b_pcm);
+    ExactSinks sk;
+    sk.power = (double*)base; base += al(nb * 8);
+    sk.q = (long long*)base; base += al(nb * 8);
+    sk.col = (int32_t*)base; base += al(nb * 4);
+    sk.row = (int32_t*)base;
+    HIPCHK(e, hipMemcpyAsync(d_pcm, pcm, b_pcm, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, launch_exact_frames(n, pd, d_pcm, L, S, frame0, nframes, sk, e->stream));
+    HIPCHK(e, hipMemcpyAsync(power, sk.power, nb * 8, hipMemcpyDeviceToHost, e->stream));
+    if (q) HIPCHK(e, hipMemcpyAsync(q, sk.q, nb * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(col, sk.col, nb * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(row, sk.row, nb * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return EMSPEC_OK;
 }
@@ -605,8 +764,18 @@ static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_
     const int W = e->st_W;
     const int64_t slot = c < 0 ? W : c % W;
     const DbMap m = db_map(e, e->st_n);
-    float* cells = e->d_ring + (size_t)slot * R;
+    const size_t cellb = e->exact() ? 8 : 4;   // EXACT mode: the ring holds u64 fixed-point cells
+    float* cells = reinterpret_cast<float*>(reinterpret_cast<char*>(e->d_ring) + (size_t)slot * R * cellb);
     const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
+    if (e->exact()) {
+        Plan* p;
+        int rc;
+        if ((rc = get_plan(e, e->st_n, &p))) return rc;
+        const ExactPlanDev xpd = exact_plan_dev(e, *p, e->st_hop, e->st_reassign);
+        HIPCHK(e, launch_exact_finalize(reinterpret_cast<const unsigned long long*>(cells), R, exact_db_map(e, e->st_n, xpd),
+                                        e->d_lut, (out_db || post) ? e->d_coldb : nullptr,
+                                        (out_rgba && !post) ? e->d_colrgba : nullptr, nullptr, e->stream));
+    } else
     HIPCHK(e, launch_finalize(cells, R, m, e->d_lut, (out_db || post) ? e->d_coldb : nullptr,
                               (out_rgba && !post) ? e->d_colrgba : nullptr, nullptr, e->stream));
     if (post) {
@@ -619,7 +788,7 @@ static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_
     }
     if (out_db) HIPCHK(e, hipMemcpyAsync(out_db, e->d_coldb, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
     if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba, e->d_colrgba, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
-    if (c >= 0) HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)R * 4, e->stream));
+    if (c >= 0) HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)R * cellb, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return EMSPEC_OK;
 }
@@ -636,11 +805,11 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     if (e->st_reassign < 0) {
         // first frame of a stream: set up the ring; the stream state is committed only after every allocation succeeded
         const int D = latency(n, hop, reassign), W = 2 * D + 1;
-        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 8))) return rc;   // 8: room for EXACT mode's u64 cells
         if ((rc = grow(e, (void**)&e->d_frame, &e->frame_bytes, (size_t)n * 4))) return rc;
         if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
         if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
-        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
+        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 8, e->stream));
         e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W;
         e->st_mode = 1;
     } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 1) {
@@ -659,7 +828,19 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, 
     const int64_t c = j - e->st_D;   // column completed by this frame
     const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
     if (out_column) *out_column = c >= 0 ? c : -1;
-    if (!post && (out_db || out_rgba)) {
+    if (e->exact()) {
+        // EXACT mode: u64 ring in HBM (global integer atomics), then the binary64 finalize of the finished column
+        ExactSinks xs;
+        xs.hist = reinterpret_cast<unsigned long long*>(e->d_ring);
+        xs.hist_slots = e->st_W;
+        xs.total_cols = INT64_MAX;
+        xs.ring = 1;
+        xs.col_offset = j;
+        HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, launch_exact_frames(n, exact_plan_dev(e, *p, hop, reassign), e->d_frame, n, 1, 0, 1, xs, e->stream));
+        e->st_fed = j + 1;
+        if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
+    } else if (!post && (out_db || out_rgba)) {
         // One launch, no DMA: the frame's workgroup reads the samples from page-locked host memory, scatters,
         // and emits the finished column straight into page-locked host memory (FrameSinks::fin_*).
         if (e->h_frame_bytes < (size_t)n * 4) {
@@ -730,14 +911,14 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
     if (e->st_reassign < 0) {
         const int D = latency(n, hop, reassign);
         const int W = 2 * D + kPushFrames;
-        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 4))) return rc;
+        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 8))) return rc;
         for (int b = 0; b < 2; ++b)
             if ((rc = grow(e, (void**)&e->d_sbuf[b], &e->sbuf_bytes[b], cap * 4))) return rc;
         if ((rc = grow(e, (void**)&e->d_pushdb, &e->pushdb_bytes, (size_t)kPushFrames * R * 4))) return rc;
         if ((rc = grow(e, (void**)&e->d_pushrgba, &e->pushrgba_bytes, (size_t)kPushFrames * R * 4))) return rc;
         if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
         if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
-        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 4, e->stream));
+        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 8, e->stream));
         e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W; e->st_mode = 2;
         e->st_have = 0; e->st_cur = 0;
     }
@@ -745,6 +926,10 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
     if ((rc = get_plan(e, n, &p))) return rc;
     const PlanDev pd = plan_dev(e, *p, hop, reassign);
     const DbMap m = db_map(e, n);
+    const bool exact = e->exact();
+    const ExactPlanDev xpd = exact ? exact_plan_dev(e, *p, hop, reassign) : ExactPlanDev{};
+    const ExactDbMap xm = exact ? exact_db_map(e, n, xpd) : ExactDbMap{};
+    const size_t cellb = exact ? 8 : 4;
     const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
     if (post && !e->d_pstate) {
         HIPCHK(e, hipMalloc(&e->d_pstate, (size_t)(4096 + 4) * 4));
@@ -777,18 +962,28 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, i
         sk.total_cols = INT64_MAX;
         sk.ring = 1;
         sk.col_offset = j0;   // buffered sample 0 is the first sample of absolute frame j0
+        if (exact) {
+            ExactSinks xs;
+            xs.hist = reinterpret_cast<unsigned long long*>(e->d_ring);
+            xs.hist_slots = W; xs.total_cols = INT64_MAX; xs.ring = 1; xs.col_offset = j0;
+            HIPCHK(e, launch_exact_frames(n, xpd, buf, e->st_have, 1, 0, M, xs, e->stream));
+        } else
         HIPCHK(e, launch_frames(n, pd, buf, e->st_have, 1, 0, M, sk, e->stream));
         // frames j0..j0+M-1 complete columns j0-D .. j0+M-1-D
         const int64_t c0 = std::max<int64_t>(j0 - D, 0), c1 = j0 + M - D;   // [c0, c1)
         for (int64_t c = c0; c < c1;) {
             const int64_t slot = c % W;
             const int64_t run = std::min<int64_t>(c1 - c, W - slot);        // contiguous slots before the ring wraps
-            float* cells = e->d_ring + (size_t)slot * R;
+            float* cells = reinterpret_cast<float*>(reinterpret_cast<char*>(e->d_ring) + (size_t)slot * R * cellb);
             float* ddb = e->d_pushdb + (size_t)(c - c0) * R;
             uint8_t* drg = e->d_pushrgba + (size_t)(c - c0) * R * 4;
+            if (exact)
+                HIPCHK(e, launch_exact_finalize(reinterpret_cast<const unsigned long long*>(cells), run * R, xm, e->d_lut,
+                                                (out_db || post) ? ddb : nullptr, (out_rgba && !post) ? drg : nullptr, nullptr, e->stream));
+            else
             HIPCHK(e, launch_finalize(cells, run * R, m, e->d_lut, (out_db || post) ? ddb : nullptr,
                                       (out_rgba && !post) ? drg : nullptr, nullptr, e->stream));
-            HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)run * R * 4, e->stream));
+            HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)run * R * cellb, e->stream));
             c += run;
         }
         const int64_t nc = c1 > c0 ? c1 - c0 : 0;

@@ -63,6 +63,18 @@ struct DbMap {           // stage "dB + colour"
     float gate;          // gate_db
 };
 
+// EXACT mode (exact.hip.inc): the same plan in binary64, plus the fixed point of the histogram
+struct ExactPlanDev {
+    const double2* tw;   // N/2 entries (cos, -sin)(2 pi q / N) in binary64, same symmetries as the float32 table
+    const double* ebin;  // rows+1 row edges in DFT-bin units, binary64
+    int rows, log_rows, D, reassign, hop;
+    double tscale;       // (N/2)/hop
+    double pfloor;       // gate on |X_h|^2
+    double pmax;         // upper gate = 2^61 / qscale
+    double qscale;       // fixed-point units per unit of |X_h|^2: 2^52 / (N/4)^2, a power of two
+};
+struct ExactDbMap { double scale, lo, inv_range, gate, inv_q; };
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // canonical complex product d * w  (see oracle fft_dif_f32)

@@ -17,6 +17,9 @@ struct Plan {
     float2* d_tw = nullptr;
     float* d_ebin = nullptr;
     std::vector<float> h_tw, h_ebin;
+    // EXACT mode (cfg.mode == EMSPEC_MODE_EXACT): the binary64 tables
+    double2* d_tw64 = nullptr;
+    double* d_ebin64 = nullptr;
 };
 }  // namespace emspec
 
@@ -33,6 +36,7 @@ struct emspec_engine {
     // batch workspace (generic path per-bin records; host-API staging)
     float* d_hist = nullptr;
     size_t hist_bytes = 0;
+    bool exact() const { return cfg.mode == EMSPEC_MODE_EXACT; }
     char* d_stage = nullptr;
     size_t stage_bytes = 0;
     // streaming state

@@ -30,6 +30,33 @@ struct FrameSinks {
     DbMap fin_map{};
 };
 
+// Where the exact-mode frame kernels send their per-bin results (exact.hip.inc)
+struct ExactSinks {
+    // parity dump (power/col/row together, q optional): [stream][frame][K]
+    double* power = nullptr;
+    int32_t* col = nullptr;
+    int32_t* row = nullptr;
+    long long* q = nullptr;
+    // per-bin records for exact_tile_scatter_kernel: [stream][frame][exact_record_stride(n)] of the bin's fixed-point
+    // energy and key = (dcol+32768)<<16 | row, or 0xFFFFFFFF when dropped
+    long long* rec_q = nullptr;
+    uint32_t* rec_key = nullptr;
+    // histogram (global u64 atomics; the streaming ring): hist[stream][slots][rows]
+    unsigned long long* hist = nullptr;
+    int64_t hist_slots = 0;
+    int64_t total_cols = 0;
+    int32_t ring = 0;
+    int64_t col_offset = 0;
+};
+hipError_t launch_exact_frames(int n, const ExactPlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
+                               int64_t nframes, const ExactSinks& sinks, hipStream_t st);
+int exact_record_stride(int n);
+hipError_t launch_exact_tile_scatter(const long long* rec_q, const uint32_t* rec_key, int n, const ExactPlanDev& pl,
+                                     const ExactDbMap& m, const uint8_t* lut, int S, int64_t C, float* db, uint8_t* rgba,
+                                     uint8_t* index, hipStream_t st);
+hipError_t launch_exact_finalize(const unsigned long long* cells, int64_t ncells, const ExactDbMap& m, const uint8_t* lut,
+                                 float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
+
 bool supported_fft(int n);
 
 // One workgroup per frame: frames [frame0, frame0+nframes) of each of S streams.

@@ -627,3 +627,4 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
 #include "fused.hip.inc"
 #include "post.hip.inc"
 #include "pack.hip.inc"
+#include "exact.hip.inc"

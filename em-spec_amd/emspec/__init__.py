@@ -21,6 +21,7 @@ DIAG_LIB_PATH = os.path.join(ROOT, "libemspec_diag.so")
 ABI_VERSION = 1
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_COMM = -1, -2, -3, -4, -5, -6
+MODE_FAST, MODE_EXACT = 0, 1
 COMM_ID_BYTES = 128
 GATHER_LOOPBACK = 1
 
@@ -33,11 +34,12 @@ SYMBOLS = [
     "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
     "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
     "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
+    "emspec_parity_dump_exact",
 ]
 
 
 class Config(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("rows", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("rows", C.c_int32), ("mode", C.c_int32),
                 ("sample_rate", C.c_float), ("fmin_hz", C.c_float), ("fmax_hz", C.c_float), ("gain", C.c_float),
                 ("db_top", C.c_float), ("db_range", C.c_float), ("gate_db", C.c_float), ("power_floor", C.c_float)]
 
@@ -100,6 +102,7 @@ def load(diag=False):
     lib.emspec_parity_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emspec_parity_dump_device.argtypes = lib.emspec_parity_dump.argtypes + [C.c_void_p]
+    lib.emspec_parity_dump_exact.argtypes = lib.emspec_parity_dump.argtypes + [C.c_void_p]
     lib.emspec_uses_fused.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.emspec_set_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.emspec_get_row_edges_hz.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -385,6 +388,23 @@ class Engine:
         self._chk(self._lib.emspec_parity_dump(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), frame0,
                                                nframes, _np_ptr(pw), _np_ptr(col), _np_ptr(row)))
         return pw, col, row
+
+    def parity_dump_exact(self, pcm, n, hop, reassign=True, frame0=0, nframes=None):
+        """EXACT-mode engine: (power float64, col, row, q int64), each [S][nframes][n/2+1]."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        S, L = pcm.shape
+        if nframes is None:
+            nframes = num_columns(L, n, hop) - frame0
+        K = n // 2 + 1
+        pw = np.empty((S, nframes, K), np.float64)
+        col = np.empty((S, nframes, K), np.int32)
+        row = np.empty((S, nframes, K), np.int32)
+        q = np.empty((S, nframes, K), np.int64)
+        self._chk(self._lib.emspec_parity_dump_exact(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), frame0,
+                                                     nframes, _np_ptr(pw), _np_ptr(col), _np_ptr(row), _np_ptr(q)))
+        return pw, col, row, q
 
     # -- streaming: the renderer's computeSpectrogramColumn -------------------------
     def column(self, frame, hop, reassign=True, want_rgba=False):

@@ -62,7 +62,7 @@ typedef struct emspec_config {
     int32_t abi_version;   /* must be EMSPEC_ABI_VERSION */
     int32_t device;        /* HIP device ordinal */
     int32_t rows;          /* R: log-frequency rows per column (64..4096), default 1024 */
-    int32_t reserved0;
+    int32_t mode;          /* EMSPEC_MODE_FAST (0, default) or EMSPEC_MODE_EXACT; see below */
     float sample_rate;     /* Hz, default 48000 */
     float fmin_hz;         /* lowest row edge, default 20 */
     float fmax_hz;         /* highest row edge, default sample_rate/2 */
@@ -72,6 +72,22 @@ typedef struct emspec_config {
     float gate_db;         /* cells below this dB are drawn as index 0 ("Noise Gate", README.md:47) */
     float power_floor;     /* bins with |X_h|^2 below this are not reassigned/accumulated */
 } emspec_config;
+
+/*
+ * Arithmetic modes [BUILD-DEFINED] (north_star: results must match the reference JS path "within 1e-4 relative on
+ * magnitude and exactly on reassigned integer (time,freq) bin indices"; JavaScript arithmetic is IEEE binary64).
+ *   EMSPEC_MODE_FAST   float32 throughout: indices are exact against the float32 bit model; against a
+ *                      binary64 evaluation a few 1e-4 of the bins that sit on a cell edge land in the neighbouring
+ *                      cell, and cells are summed in arrival order (dB reproducible to a few ulp).
+ *   EMSPEC_MODE_EXACT  binary64 from the frame to the indices, energy summed in 64-bit fixed point (order-
+ *                      independent), dB through a specified binary64 polynomial: (column,row) agree
+ *                      with a float64 implementation of the three-window method on every bin, and dB / palette index /
+ *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes.  Inputs must stay
+ *                      within |x| <= 4 (the fixed point covers 2^11 full-scale-sine powers per cell).  Same entry points;
+ *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 4x slower than the fast mode.
+ */
+#define EMSPEC_MODE_FAST 0
+#define EMSPEC_MODE_EXACT 1
 
 typedef struct emspec_engine emspec_engine;
 
@@ -232,7 +248,18 @@ int emspec_parity_dump(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
                        int64_t frame0, int64_t nframes,
                        float* power, int32_t* col, int32_t* row);
 
-/* Device-pointer form of the same (all five buffers on the device). */
+/*
+ * Parity dump of an EXACT-mode engine (EMSPEC_ERR_STATE on a fast-mode engine, and vice versa for emspec_parity_dump):
+ *   power[s][f][k] = |X_h[k]|^2 (binary64), col / row as above, q[s][f][k] (optional, may be NULL) = the bin's
+ *   fixed-point energy as it is added to the histogram (0 when the bin is dropped): round(power * 2^52 / (n/4)^2).
+ * Host pointers.
+ */
+int emspec_parity_dump_exact(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
+                             int32_t n, int32_t hop, int32_t reassign,
+                             int64_t frame0, int64_t nframes,
+                             double* power, int32_t* col, int32_t* row, int64_t* q);
+
+/* Device-pointer form of emspec_parity_dump (all five buffers on the device). */
 int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
                               int64_t L, int32_t n, int32_t hop, int32_t reassign,
                               int64_t frame0, int64_t nframes,

@@ -73,6 +73,12 @@ static void make_edges64(const eo_cfg* c, double* e) {
         e[r] = (double)c->fmin_hz * pow(ratio, (double)r / (double)c->rows) *
                (double)c->n / (double)c->sample_rate;
 }
+/* float64 row edges in DFT-bin units (rows+1): what eo_frames_f64 and the exact mode (emspec_exact.c) compare against */
+int eo_edges64(const eo_cfg* c, double* e) {
+    if (check_cfg(c) || !e) return -1;
+    make_edges64(c, e);
+    return 0;
+}
 int eo_tables(const eo_cfg* c, float* twiddle, float* ebin) {
     if (check_cfg(c)) return -1;
     if (twiddle) make_twiddle(c->n, twiddle);

@@ -13,7 +13,8 @@
  * analytic known-answer tests and an independent numpy formulation
  * (oracle/ref_numpy.py), not by reference outputs.
  *
- * Two restatements live here:
+ * Three restatements live here (the third, eo_frames_exact / eo_batch_exact in emspec_exact.c, is the binary64
+ * bit model of EMSPEC_MODE_EXACT):
  *   eo_frames_f64  float64, the textbook method: three explicitly windowed
  *                  DFTs (h, (n-c)h, dh/dn) -> P, t-hat, f-hat.  "Truth".
  *   eo_frames_f32  float32 BIT MODEL of the arithmetic the HIP kernels are
@@ -60,6 +61,21 @@ int eo_batch_f32(const eo_cfg* c, const float* pcm, int32_t S, int64_t L,
 int eo_hist_f32(const eo_cfg* c, const float* pcm, int32_t S, int64_t L,
                 float* hist, int32_t threads);
 int eo_max_threads(void);
+
+/* float64 row edges in DFT-bin units (rows+1 doubles): the table eo_frames_f64 and the exact mode compare against */
+int eo_edges64(const eo_cfg* c, double* edges);
+
+/* ---- EXACT mode (emspec_exact.c): the binary64 bit model of EMSPEC_MODE_EXACT ----
+ * eo_frames_exact: per-bin power (double), absolute column, row and the bin's fixed-point energy q
+ *                  (0 when the bin is dropped), each [nframes][n/2+1]; any output may be NULL.
+ * eo_batch_exact:  whole pipeline with the int64 histogram: db (float32 of the binary64 dB) / rgba / index
+ *                  [S][C][R], hist (optional) the int64 cell sums.  Order-independent by construction.
+ * eo_exact_db:     the specified 10*log10 evaluation (no libm), exposed for the GPU probe test. */
+int eo_frames_exact(const eo_cfg* c, const float* pcm, int64_t L, int64_t frame0, int64_t nframes,
+                    double* power, int32_t* col, int32_t* row, int64_t* q);
+int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, const uint8_t* lut, float* db,
+                   uint8_t* rgba, uint8_t* index, int64_t* hist, int32_t threads);
+double eo_exact_db(double x);
 
 /* emspec_cpu_fast.c: the same pipeline written for speed on a CPU (Stockham radix-4 FFT, ring histogram, vectorised
  * dB), for bench.py's cpu_baseline leg.  Not bit-identical to the bit model; checked against it at the test tolerance. */

@@ -34,7 +34,7 @@ def make_cfg(n, hop, reassign=True, **kw):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("emspec_oracle.c", "emspec_cpu_fast.c", "emspec_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("emspec_oracle.c", "emspec_exact.c", "emspec_cpu_fast.c", "emspec_oracle.h")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libemspec_oracle.so"])
     return _SO
@@ -49,6 +49,8 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         _lib.eo_max_threads.restype = C.c_int
+        _lib.eo_exact_db.restype = C.c_double
+        _lib.eo_exact_db.argtypes = [C.c_double]
     return _lib
 
 
@@ -132,6 +134,51 @@ def batch_f32(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
                             _p(db, C.c_float), _p(rgba, C.c_uint8), _p(idx, C.c_uint8), C.c_int32(threads))
     assert rc == 0, rc
     return db, rgba, idx
+
+
+def edges64(cfg):
+    e = np.empty(cfg.rows + 1, np.float64)
+    assert lib().eo_edges64(C.byref(cfg), _p(e, C.c_double)) == 0
+    return e
+
+
+def frames_exact(cfg, pcm, frame0, nframes):
+    """EXACT-mode bit model, one stream: (power float64, col, row, q int64), each [nframes][n/2+1]."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    K = cfg.n // 2 + 1
+    pw = np.empty((nframes, K), np.float64)
+    col = np.empty((nframes, K), np.int32)
+    row = np.empty((nframes, K), np.int32)
+    q = np.empty((nframes, K), np.int64)
+    rc = lib().eo_frames_exact(C.byref(cfg), _p(pcm, C.c_float), C.c_int64(pcm.size), C.c_int64(frame0),
+                               C.c_int64(nframes), _p(pw, C.c_double), _p(col, C.c_int32), _p(row, C.c_int32),
+                               _p(q, C.c_int64))
+    assert rc == 0, rc
+    return pw, col, row, q
+
+
+def batch_exact(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
+    """EXACT-mode bit model, whole pipeline: (db, rgba, index, hist int64 or None)."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    if pcm.ndim == 1:
+        pcm = pcm[None]
+    S, L = pcm.shape
+    Cn = num_columns(L, cfg.n, cfg.hop)
+    db = np.empty((S, Cn, cfg.rows), np.float32) if "db" in want else None
+    rgba = np.empty((S, Cn, cfg.rows, 4), np.uint8) if "rgba" in want else None
+    idx = np.empty((S, Cn, cfg.rows), np.uint8) if "index" in want else None
+    hist = np.empty((S, Cn, cfg.rows), np.int64) if "hist" in want else None
+    if lut is not None:
+        lut = np.ascontiguousarray(lut, np.uint8)
+    rc = lib().eo_batch_exact(C.byref(cfg), _p(pcm, C.c_float), C.c_int32(S), C.c_int64(L), _p(lut, C.c_uint8),
+                              _p(db, C.c_float), _p(rgba, C.c_uint8), _p(idx, C.c_uint8), _p(hist, C.c_int64),
+                              C.c_int32(threads))
+    assert rc == 0, rc
+    return db, rgba, idx, hist
+
+
+def exact_db(x):
+    return float(lib().eo_exact_db(float(x)))
 
 
 def max_threads():
