@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the side measurements of the other named configs")
     ap.add_argument("--force-chunks", type=int, default=0, help="N=1: launch per stream-chunk as the N>1 path does (no gather)")
     ap.add_argument("--reassign", type=int, default=1)
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact"],
+                    help="exact = EMSPEC_MODE_EXACT (binary64 + 64-bit fixed-point histogram, DESIGN.md 3.7); the default line is "
+                         "the fast mode and reports the exact mode's rate in `configs`")
     ap.add_argument("--gather", default="lib", choices=["lib", "torch", "loopback", "dist-loopback"],
                     help="lib = libemspec's RCCL gather (default); torch = torch.distributed.gather of raw columns; "
                          "loopback = N=1 rehearsal: the rank's own columns go through pack + RCCL self send/recv + expand; "
@@ -275,7 +278,7 @@ def main():
         n, hop = 4096, 256
     S = args.streams or (1 if args.workload == "single" else 64)     # streams per GPU (the job has world x S)
     L = 1 << args.log2_samples
-    eng = emspec.Engine(device=dev_index)
+    eng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT if args.mode == "exact" else emspec.MODE_FAST)
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
     if args.workload == "paritydump":
@@ -508,8 +511,8 @@ def main():
                       f"reassigned spectrogram columns/sec ({n}-pt, hop {hop}, 48 kHz)",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl, "streams_per_gpu": S_nominal, "streams_per_rank": counts, "samples_per_stream": L, "columns_per_step": cols_per_step,
+            "vs_baseline": None, "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
+            "config": {"workload": wl + ("; EXACT mode (binary64, 64-bit fixed-point histogram)" if args.mode == "exact" else ""), "streams_per_gpu": S_nominal, "streams_per_rank": counts, "samples_per_stream": L, "columns_per_step": cols_per_step,
                        "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True),
                        "sources_sha": sources_sha()},
             "roofline": rf,
@@ -565,6 +568,19 @@ def main():
                 c4["roofline"]["traffic_source"] = f"{p4['file']}{'' if f4 else ' (STALE: kernels changed since, withheld)'}"
             measure("64 streams, FFT 4096, hop 256, reassignment OFF", 64, L, 4096, 256, False, 3)
             measure("64 streams, FFT 1024, hop 256, reassignment ON", 64, 1 << 20, 1024, 256, True, 5)
+            # EXACT mode (binary64 + 64-bit fixed point: indices equal to a float64 implementation, bytes reproducible) on
+            # a second engine: configs[2] on 16 of the 64 streams (the record workspace is 0.4 GB per stream) and configs[4]
+            xeng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT)
+            for name, Sx, nx, hx, reps in (("EXACT mode, configs[2] shape: 16 streams, FFT 4096, hop 256, reassignment ON", 16, 4096, 256, 3),
+                                           ("EXACT mode, configs[4] shape: 8 streams, FFT 16384, hop 512, reassignment ON", 8, 16384, 512, 2)):
+                Cx = emspec.num_columns(L, nx, hx)
+                px = pcm[:Sx].contiguous()
+                dbx = db.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
+                ixx = idx.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
+                ms = time_launches(lambda: xeng.batch_device(px, nx, hx, True, db=dbx, index=ixx, stream=cur), cur, reps)
+                cfgs[name] = {"columns_per_s": Sx * Cx / (ms * 1e-3), "columns_per_launch": Sx * Cx, "kernel_ms": ms,
+                              "dtype": "f64", "roofline": roofline(Sx * Cx, 4 * hx + 5 * R, ms)}
+            xeng.close()
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
 

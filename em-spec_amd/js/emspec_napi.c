@@ -105,6 +105,13 @@ static napi_value Create(napi_env env, napi_callback_info info) {
             if (get_number_prop(env, argv[0], "dbRange", &d)) cfg.db_range = (float)d;
             if (get_number_prop(env, argv[0], "gateDb", &d)) cfg.gate_db = (float)d;
             if (get_number_prop(env, argv[0], "powerFloor", &d)) cfg.power_floor = (float)d;
+            /* exact: true -> EMSPEC_MODE_EXACT (binary64 + 64-bit fixed-point histogram: indices equal to a float64
+             * implementation, reproducible bytes); default EMSPEC_MODE_FAST */
+            napi_value ex; bool has = false, on = false;
+            if (napi_has_named_property(env, argv[0], "exact", &has) == napi_ok && has &&
+                napi_get_named_property(env, argv[0], "exact", &ex) == napi_ok &&
+                napi_coerce_to_bool(env, ex, &ex) == napi_ok && napi_get_value_bool(env, ex, &on) == napi_ok && on)
+                cfg.mode = EMSPEC_MODE_EXACT;
         }
     }
     emspec_engine* e = NULL;

@@ -14,7 +14,8 @@
 const native = require('./emspec.node');
 
 class Engine {
-  /** config: {device, rows, sampleRate, fminHz, fmaxHz, gain, dbTop, dbRange, gateDb, powerFloor} */
+  /** config: {device, rows, sampleRate, fminHz, fmaxHz, gain, dbTop, dbRange, gateDb, powerFloor, exact}
+   *  exact: true = EMSPEC_MODE_EXACT (binary64 arithmetic, 64-bit fixed-point histogram; include/emspec.h) */
   constructor(config = {}) {
     this.rows = native.rows(config);
     this._h = native.create(config);

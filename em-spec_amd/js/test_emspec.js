@@ -37,6 +37,34 @@ function checkAgainstJsOracle(fftSize, hop, reassign, frames) {
   eng.destroy();
 }
 
+/* EXACT mode ({exact: true}: binary64 + 64-bit fixed-point histogram) against the plain-JS float64 method: every cell the
+ * float64 method puts above -60 dB within 8.7e-4 dB (= 1e-4 relative on magnitude; no bin changes cell), and the streaming
+ * call gives the SAME float32 bits as the batched call (integer accumulation is order-independent). */
+function checkExactAgainstJsOracle(fftSize, hop, frames) {
+  const eng = em.createEngine({ exact: true });
+  const L = fftSize + hop * (frames - 1);
+  const pcm = synth(L);
+  const R = eng.rows;
+  const want = ref.columnsDb(pcm, fftSize, hop, true, frames);
+  const D = em.latencyColumns(fftSize, hop, true);
+  const got = new Float32Array(frames * R);
+  for (let j = 0; j < frames; j++) {
+    const col = eng.computeSpectrogramColumn(pcm.subarray(j * hop, j * hop + fftSize), fftSize, hop, true);
+    if (eng.lastColumn >= 0) got.set(col, eng.lastColumn * R);
+  }
+  for (let k = 0; k < Math.min(D, frames); k++) { const col = eng.flush(); got.set(col, eng.lastColumn * R); }
+  const batch = new Float32Array(frames * R);
+  eng.computeColumns(pcm, 1, L, fftSize, hop, true, { db: batch });
+  let strong = 0, worst = 0;
+  for (let i = 0; i < want.length; i++) {
+    if (got[i] !== batch[i]) throw new Error('exact mode: streaming and batch differ at cell ' + i);
+    if (want[i] > -60) { strong++; worst = Math.max(worst, Math.abs(batch[i] - want[i])); }
+  }
+  if (!(strong > 100 && worst < 8.7e-4)) throw new Error('exact mode vs plain-JS float64 oracle: ' + strong + ' strong cells, worst ' + worst + ' dB');
+  eng.destroy();
+  return worst;
+}
+
 /* multi-GPU entry points on one rank: communicator creation, batch + RCCL gather (world 1: the root's own columns) */
 function checkGatherOneRank() {
   const eng = em.createEngine({});
@@ -174,6 +202,7 @@ async function checkAsync() {
 
 checkAgainstJsOracle(1024, 256, false, 40);
 checkAgainstJsOracle(4096, 256, true, 48);
+const wx = checkExactAgainstJsOracle(4096, 256, 48);
 checkGatherOneRank();
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);
@@ -182,5 +211,5 @@ checkPush(1024, 256, false, 90);
 const col = em.computeSpectrogramColumn(new Float32Array(1024), 1024, 256, false);
 if (col.length !== 1024) throw new Error('module-level call');
 checkAsync().then(() => {
-  console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2));
+  console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2), '; exact mode vs plain-JS float64, worst strong cell', wx.toExponential(2), 'dB');
 }).catch((e) => { console.error(e); process.exit(1); });
