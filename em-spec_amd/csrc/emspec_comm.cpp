@@ -43,6 +43,9 @@ struct emspec_comm_state {
     uint8_t* d_recv = nullptr; size_t recv_bytes = 0;        // root: the other ranks' images, back to back
     uint64_t* d_sizes = nullptr;                             // [world][2] (image bytes, columns) after the all-gather
     uint64_t* h_sizes = nullptr;                             // page-locked copy
+    // layout of the last EMSPEC_GATHER_PACKED gather on the root: per rank (offset in gathered_dev, image bytes, columns)
+    std::vector<uint64_t> packed_layout;
+    uint64_t* h_dir = nullptr;                               // page-locked directory, copied to the head of gathered_dev
 };
 
 namespace {
@@ -77,6 +80,7 @@ void comm_destroy(emspec_engine* e) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     (void)hipFree(c->d_wire); (void)hipFree(c->d_scratch); (void)hipFree(c->d_recv); (void)hipFree(c->d_sizes);
     if (c->h_sizes) (void)hipHostFree(c->h_sizes);
+    if (c->h_dir) (void)hipHostFree(c->h_dir);
     delete c;
     e->comm = nullptr;
 }
@@ -107,6 +111,7 @@ int emspec_comm_init(emspec_engine* e, const uint8_t* id_bytes, int32_t rank, in
     c->world = world;
     HIPCHK(e, hipMalloc(&c->d_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1)));
     HIPCHK(e, hipHostMalloc((void**)&c->h_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1), hipHostMallocDefault));
+    HIPCHK(e, hipHostMalloc((void**)&c->h_dir, sizeof(uint64_t) * 4 * (size_t)world + 64, hipHostMallocDefault));
     return EMSPEC_OK;
 }
 
@@ -180,15 +185,17 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     const int R = e->cfg.rows, world = c->world, me = c->rank;
     const bool is_root = me == root;
     const bool loopback = (flags & EMSPEC_GATHER_LOOPBACK) != 0;   // the root's own columns take the wire too (tests)
+    const bool packed = (flags & EMSPEC_GATHER_PACKED) != 0;       // the root keeps the images packed (no expand)
     const size_t col_bytes = (size_t)columns * R;
     const bool i_send = !is_root || loopback;
+    const bool i_pack = i_send || packed;                          // packed: the root's own columns become an image too
     int rc;
     if (wire_bytes_sent) *wire_bytes_sent = 0;
     c->h_sizes[2 * world] = (uint64_t)columns;   // page-locked: read by the async copy below
 
     // ---- this rank's wire image
     uint64_t* d_total = nullptr;
-    if (i_send) {
+    if (i_pack) {
         if ((rc = ensure_wire_buffers(e, c, columns))) return rc;
         HIPCHK(e, launch_wire_pack(index_dev, columns, R, c->d_wire, c->d_scratch, st));
         d_total = wire_total_ptr(c->d_scratch, columns);
@@ -212,22 +219,30 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
 
     // ---- the exchange: one grouped set of point-to-point transfers, every rank -> root
     std::vector<size_t> off((size_t)world + 1, 0), dst_off((size_t)world + 1, 0);
+    const size_t dir_bytes = packed ? ((sizeof(uint64_t) * 4 * (size_t)world + 255) & ~(size_t)255) : 0;
     if (is_root) {
         for (int r = 0; r < world; ++r) {
             off[r + 1] = off[r] + (((size_t)c->h_sizes[2 * r] + 255) & ~(size_t)255);
             dst_off[r + 1] = dst_off[r] + (size_t)c->h_sizes[2 * r + 1] * R;
         }
-        if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc;
+        if (!packed && (rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc;
     }
     // a gathered buffer that cannot hold the announced shards is the root's error alone: the transfers below still run
     // (into the root's own receive buffer), so that the other ranks' sends complete, and only the expand is skipped
-    const bool fits = !is_root || dst_off[world] <= (size_t)(gathered_capacity > 0 ? gathered_capacity : 0);
+    const size_t need_cap = packed ? dir_bytes + off[world] : dst_off[world];
+    const bool fits = !is_root || need_cap <= (size_t)(gathered_capacity > 0 ? gathered_capacity : 0);
+    uint8_t* recv_base = c->d_recv;
+    if (is_root && packed) {
+        if (fits) recv_base = gathered_dev + dir_bytes;            // the images land where they stay
+        else if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc; else recv_base = c->d_recv;
+    }
     NCCLCHK(e, ncclGroupStart());
     ncclResult_t nr = ncclSuccess;
     if (i_send && c->h_sizes[2 * me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[2 * me], ncclUint8, root, c->comm, st);
     if (is_root)
         for (int r = 0; r < world && nr == ncclSuccess; ++r)
-            if (c->h_sizes[2 * r] > 0) nr = ncclRecv(c->d_recv + off[r], (size_t)c->h_sizes[2 * r], ncclUint8, r, c->comm, st);
+            if (c->h_sizes[2 * r] > 0 && (r != me || loopback))
+                nr = ncclRecv(recv_base + off[r], (size_t)c->h_sizes[2 * r], ncclUint8, r, c->comm, st);
     const ncclResult_t ge = ncclGroupEnd();
     if (nr != ncclSuccess) return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr));
     NCCLCHK(e, ge);
@@ -236,6 +251,22 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
 
     // ---- root: expand every image into its rank's block of the gathered buffer (blocks in rank order, each as long as
     // that rank's shard); its own columns are a device copy
+    if (is_root && packed) {
+        // directory (per rank: offset from the start of gathered_dev, image bytes, columns, 0) + the images, 256-byte
+        // aligned, in rank order; the root's own image is a device copy of what it packed above.  Expand any of them
+        // later with emspec_wire_unpack(gathered_dev + offset, bytes, columns, ...): emspec_gather_packed_layout.
+        c->packed_layout.assign((size_t)world * 3, 0);
+        for (int r = 0; r < world; ++r) {
+            c->h_dir[4 * r] = c->packed_layout[3 * r] = (uint64_t)(dir_bytes + off[r]);
+            c->h_dir[4 * r + 1] = c->packed_layout[3 * r + 1] = c->h_sizes[2 * r];
+            c->h_dir[4 * r + 2] = c->packed_layout[3 * r + 2] = c->h_sizes[2 * r + 1];
+            c->h_dir[4 * r + 3] = 0;
+        }
+        HIPCHK(e, hipMemcpyAsync(gathered_dev, c->h_dir, sizeof(uint64_t) * 4 * (size_t)world, hipMemcpyHostToDevice, st));
+        if (!loopback)
+            HIPCHK(e, hipMemcpyAsync(gathered_dev + dir_bytes + off[me], c->d_wire, (size_t)c->h_sizes[2 * me], hipMemcpyDeviceToDevice, st));
+        return EMSPEC_OK;
+    }
     if (is_root) {
         for (int r = 0; r < world; ++r) {
             uint8_t* dst = gathered_dev + dst_off[r];
@@ -246,6 +277,17 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
             HIPCHK(e, launch_wire_unpack(c->d_recv + off[r], (int64_t)c->h_sizes[2 * r + 1], R, dst, st));
         }
     }
+    return EMSPEC_OK;
+}
+
+int emspec_gather_packed_layout(const emspec_engine* e, int32_t rank, int64_t* offset, int64_t* bytes, int64_t* columns) {
+    if (!e || !e->comm || !e->comm->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator");
+    const emspec_comm_state* c = e->comm;
+    if (rank < 0 || rank >= c->world || c->packed_layout.size() != (size_t)c->world * 3)
+        return fail(e, EMSPEC_ERR_STATE, "no EMSPEC_GATHER_PACKED gather has completed on this engine as the root");
+    if (offset) *offset = (int64_t)c->packed_layout[3 * rank];
+    if (bytes) *bytes = (int64_t)c->packed_layout[3 * rank + 1];
+    if (columns) *columns = (int64_t)c->packed_layout[3 * rank + 2];
     return EMSPEC_OK;
 }
 

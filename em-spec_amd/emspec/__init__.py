@@ -24,6 +24,7 @@ ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_COMM = -1, -2, 
 MODE_FAST, MODE_EXACT = 0, 1
 COMM_ID_BYTES = 128
 GATHER_LOOPBACK = 1
+GATHER_PACKED = 2
 
 SYMBOLS = [
     "emspec_default_config", "emspec_create", "emspec_destroy", "emspec_last_error", "emspec_set_colormap",
@@ -34,7 +35,7 @@ SYMBOLS = [
     "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
     "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
     "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
-    "emspec_parity_dump_exact",
+    "emspec_parity_dump_exact", "emspec_gather_packed_layout",
 ]
 
 
@@ -118,6 +119,7 @@ def load(diag=False):
     lib.emspec_comm_world.argtypes = [C.c_void_p]
     lib.emspec_gather_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_uint32,
                                           C.c_void_p, C.POINTER(C.c_int64)]
+    lib.emspec_gather_packed_layout.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.emspec_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     lib.emspec_wire_bound.restype = C.c_int64
@@ -327,8 +329,10 @@ class Engine:
     def comm_world(self):
         return int(self._lib.emspec_comm_world(self._h))
 
-    def gather_columns(self, index_t, root=0, out=None, stream=None, loopback=False):
-        """index_t: contiguous uint8 CUDA tensor [..., rows] of this rank's finished columns; out (root only):
+    def gather_columns(self, index_t, root=0, out=None, stream=None, loopback=False, packed=False):
+        """packed=True: the root keeps the ranks' wire images packed in `out` (directory + images; expand on demand with
+        wire_unpack at gather_packed_layout(rank)); capacity 256*(world+1) + sum of wire_bound over the ranks.
+        index_t: contiguous uint8 CUDA tensor [..., rows] of this rank's finished columns; out (root only):
         uint8 CUDA tensor holding the ranks' blocks in rank order ([world, ...same shape...] when the shards are equal;
         the library checks that the announced shards fit).  Returns the bytes this rank put on the wire."""
         import torch
@@ -340,8 +344,16 @@ class Engine:
         sent = C.c_int64(0)
         self._chk(self._lib.emspec_gather_columns(self._h, C.c_void_p(index_t.data_ptr()), columns, root,
                                                   C.c_void_p(out.data_ptr()) if out is not None else None,
-                                                  out.numel() if out is not None else 0, GATHER_LOOPBACK if loopback else 0, C.c_void_p(st.cuda_stream), C.byref(sent)))
+                                                  out.numel() if out is not None else 0,
+                                                  (GATHER_LOOPBACK if loopback else 0) | (GATHER_PACKED if packed else 0),
+                                                  C.c_void_p(st.cuda_stream), C.byref(sent)))
         return int(sent.value)
+
+    def gather_packed_layout(self, rank):
+        """Root, after gather_columns(packed=True): (offset in the gathered buffer, image bytes, columns) of `rank`'s image."""
+        off, nb, cols = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._lib.emspec_gather_packed_layout(self._h, rank, C.byref(off), C.byref(nb), C.byref(cols)))
+        return int(off.value), int(nb.value), int(cols.value)
 
     def batch_gather(self, pcm, n, hop, reassign=True, root=0, want_db=False):
         """Host buffers: this rank's streams -> (gathered index [world,S,C,rows] on root else None, own dB or None, wire bytes)."""

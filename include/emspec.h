@@ -302,11 +302,21 @@ int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator
  * *wire_bytes_sent (optional) receives the size of this rank's packed image (0 on the root).
  * flags: EMSPEC_GATHER_LOOPBACK makes the root's own columns take the wire as well (self send/recv; exercising
  * the whole path on a single GPU).
+ * EMSPEC_GATHER_PACKED: the root does NOT expand: gathered_dev receives a directory (per rank: u64 offset, u64 image bytes,
+ * u64 columns, u64 0; padded to 256 B) followed by every rank's wire image (the root's own included), 256-byte aligned,
+ * in rank order; capacity needed: 256 * (world + 1) + sum over ranks of emspec_wire_bound(columns_r, rows).  Nothing is
+ * lost - emspec_wire_unpack(gathered_dev + offset, bytes, columns, ...) expands any rank's block on demand (the layout
+ * is also available on the host: emspec_gather_packed_layout) - and the root, which otherwise expands world-1 images
+ * per gather beside its own column kernel, only receives.
  */
 #define EMSPEC_GATHER_LOOPBACK 1u
+#define EMSPEC_GATHER_PACKED 2u
 int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t columns, int32_t root,
                           uint8_t* gathered_dev, int64_t gathered_capacity, uint32_t flags, void* hip_stream,
                           int64_t* wire_bytes_sent);
+
+/* Root, after an EMSPEC_GATHER_PACKED gather: where rank `rank`'s image sits in gathered_dev (any pointer may be NULL). */
+int emspec_gather_packed_layout(const emspec_engine* e, int32_t rank, int64_t* offset, int64_t* bytes, int64_t* columns);
 
 /*
  * Host-buffer convenience for a rank process (the N-API addon's computeColumnsGather): this rank's S streams

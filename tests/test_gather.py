@@ -94,6 +94,23 @@ def test_rccl_gather_one_rank_loopback():
         assert ei.value.code == emspec.ERR_INVALID_ARG
         torch.cuda.synchronize()
         assert bool((small == 0x5A).all())
+        # EMSPEC_GATHER_PACKED: the root keeps the images packed (directory + images) and expands on demand
+        for lb in (True, False):
+            cap = 256 * 2 + emspec.wire_bound(S * frames, e.rows)
+            packed = torch.full((cap,), 0x77, dtype=torch.uint8, device=dev)
+            sent_p = e.gather_columns(idx, root=0, out=packed, loopback=lb, packed=True)
+            off, nb, cols = e.gather_packed_layout(0)
+            assert (off, cols) == (256, S * frames) and nb == sent == sent_p
+            torch.cuda.synchronize()
+            d = packed[:32].cpu().numpy().view(np.uint64)
+            assert tuple(int(v) for v in d[:3]) == (off, nb, cols)
+            back = torch.full((S, frames, e.rows), 0xCD, dtype=torch.uint8, device=dev)
+            e.wire_unpack(packed[off:], nb, back)
+            torch.cuda.synchronize()
+            assert torch.equal(back, idx)
+        with pytest.raises(emspec.EmspecError) as ei:   # too small for directory + image
+            e.gather_columns(idx, root=0, out=packed[:nb], loopback=True, packed=True)
+        assert ei.value.code == emspec.ERR_INVALID_ARG
         _, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",))
         d = np.abs(out[0].cpu().numpy().astype(int) - oidx.astype(int))
         assert d.max() <= 1 and np.mean(d != 0) < 1e-3
