@@ -236,6 +236,11 @@ def main():
                          "and reductions through it, two RCCL communicators in the process)")
     ap.add_argument("--root-streams", type=int, default=-1,
                     help="N>1: streams on rank 0, which also expands the gathered columns (default: try a few splits, keep the fastest)")
+    ap.add_argument("--gather-packed", action="store_true",
+                    help="N>1 / loopback: the root keeps the gathered images packed (EMSPEC_GATHER_PACKED) instead of expanding them")
+    ap.add_argument("--trial-budget-s", type=float, default=60.0,
+                    help="N>1: wall-clock budget of the stream-split trials; when it is spent the remaining splits are skipped "
+                         "(none measured: the modelled split, root 8 streams lighter per other rank, is used)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (torch gather via host tensors)")
     args = ap.parse_args()
@@ -366,7 +371,10 @@ def main():
             self.gathered = None
             if gathering and rank == 0:
                 per_rank = [chunk(c) for c in counts]
-                if gather_mode == "lib":      # [chunk] -> the ranks' blocks [streams of the chunk, C, R] one after the other
+                if gather_mode == "lib" and args.gather_packed:   # [chunk] -> directory + the ranks' packed images
+                    self.gathered = [torch.empty((256 * (world + 1) + sum(emspec.wire_bound((pr[ci][1] - pr[ci][0]) * C, R) for pr in per_rank),),
+                                                 dtype=torch.uint8, device=dev) for ci in range(nch)]
+                elif gather_mode == "lib":    # [chunk] -> the ranks' blocks [streams of the chunk, C, R] one after the other
                     self.gathered = [torch.empty((sum(pr[ci][1] - pr[ci][0] for pr in per_rank), C, R), dtype=torch.uint8, device=dev)
                                      for ci in range(nch)]
                 else:
@@ -387,9 +395,10 @@ def main():
                     # pack + size exchange + send/recv + expand on comm_stream; the call synchronises comm_stream once, while
                     # the next chunk's kernels (already enqueued on the compute stream) keep the GPU busy
                     nb = eng.gather_columns(ibuf[a:b], root=0, out=self.gathered[ci] if rank == 0 else None, stream=comm_stream,
-                                            loopback=(world == 1))
-                    self.wire_bytes[0] += nb
-                    self.wire_bytes[1] += (b - a) * C if nb else 0
+                                            loopback=(world == 1), packed=args.gather_packed)
+                    if rank != 0 or world == 1:     # (packed mode reports the root's own image size too: it is not sent)
+                        self.wire_bytes[0] += nb
+                        self.wire_bytes[1] += (b - a) * C if nb else 0
                 else:
                     src = ibuf[a:b] if args.backend == "nccl" else ibuf[a:b].cpu()   # gloo rehearsal: host tensors
                     shard.gather_columns_into(src, self.gathered[ci] if rank == 0 else None, dst=0, uneven=self.uneven)
@@ -453,21 +462,33 @@ def main():
         counts = shard.root_light_counts(world, total_streams, 0, max(args.root_streams, args.chunks))
     elif world > 1 and gathering and S >= 16:
         split_trials = []
+        t_trials = time.perf_counter()
         warm = Job(counts)             # connections, code objects and the allocator's pools: paid before any split is timed
         warm.run(2)
         del warm
+        # heaviest root first (equal shards), lightest last: if the budget runs out, what was measured includes the default
         for other in sorted({S, S + S // 32, S + S // 16, S + 3 * S // 32, S + S // 8}):
             root_count = total_streams - (world - 1) * other
             if root_count < max(1, args.chunks):
                 continue
+            # every rank must take the same decision: rank 0's clock decides, the flag is max-reduced
+            over = torch.tensor([1.0 if (time.perf_counter() - t_trials) > args.trial_budget_s else 0.0], dtype=torch.float64, device=gdev)
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+            if float(over.item()) > 0:
+                split_trials.append({"streams_per_rank": None, "skipped": f"trial budget of {args.trial_budget_s:.0f} s spent"})
+                break
             trial = shard.root_light_counts(world, total_streams, 0, root_count)
             job = Job(trial)
             job.run(1)                                     # the first gather of a run opens RCCL's connections
             el = job.run(3)
             split_trials.append({"streams_per_rank": trial, "columns_per_s": total_streams * C * 3 / el})
             del job
-        best = max(split_trials, key=lambda t: t["columns_per_s"])   # the same numbers on every rank (max-reduced times)
-        counts = best["streams_per_rank"]
+        measured = [t for t in split_trials if t.get("columns_per_s")]
+        if measured:
+            best = max(measured, key=lambda t: t["columns_per_s"])   # the same numbers on every rank (max-reduced times)
+            counts = best["streams_per_rank"]
+        else:                          # nothing measured inside the budget: the modelled split
+            counts = shard.root_light_counts(world, total_streams, 0, max(args.chunks, total_streams - (world - 1) * (S + S // 8)))
 
     job = Job(counts)
     for _ in range(max(args.warmup, 1 if gathering else 0)):   # the first gather opens RCCL's connections: never timed
@@ -480,6 +501,26 @@ def main():
         dist.all_reduce(wb, op=dist.ReduceOp.SUM)
         wire_bytes = [float(wb[0].item()), float(wb[1].item())]
     S_nominal = S
+    # every rank's own column-kernel time per step (HIP events on its launch stream), gathered for the line
+    my_kms = float(np.mean([a.elapsed_time(b) for a, b in job.kev])) if job.kev else 0.0
+    rank_kms = [my_kms]
+    if dist_on:
+        kt = torch.zeros(world, dtype=torch.float64, device=gdev)
+        kt[rank] = my_kms
+        dist.all_reduce(kt, op=dist.ReduceOp.SUM)
+        rank_kms = [float(v) for v in kt.tolist()]
+    # what the root's expand costs by itself: one other rank's chunk worth of columns, packed and expanded standalone,
+    # times the (world - 1) images per gather and the chunks per step
+    expand_ms = None
+    if rank == 0 and gathering and gather_mode == "lib" and not args.gather_packed:
+        a, b = job.bounds[0]
+        src = job.idx_bufs[0][a:b]
+        wire = torch.empty((emspec.wire_bound((b - a) * C, R),), dtype=torch.uint8, device=dev)
+        nbw = eng.wire_pack(src, wire, stream=cur)
+        back = torch.empty_like(src)
+        one = time_launches(lambda: eng.wire_unpack(wire, nbw, back, stream=cur), cur, 5)
+        expand_ms = one * max(1, world - 1) * job.nch
+        del wire, back
     S, pcm, db, idx, nch, kev = job.S, job.pcm, job.db, job.idx_bufs[0], job.nch, job.kev   # rank 0's shard, for the roofline below
 
     if rank == 0:
@@ -520,7 +561,12 @@ def main():
         if gathering:
             line["gather"] = {"path": gather_mode, "note": gather_note, "chunks_per_step": nch, "split_trials": split_trials,
                               "wire_bytes_per_column": (wire_bytes[0] / wire_bytes[1]) if wire_bytes[1] else None,
-                              "raw_bytes_per_column": R}
+                              "raw_bytes_per_column": R,
+                              "rccl_world": eng.comm_world if gather_mode == "lib" else None,      # what RCCL itself reports
+                              "root_keeps_images_packed": bool(args.gather_packed and gather_mode == "lib"),
+                              "kernel_ms_per_rank": rank_kms,                 # column-kernel time per step on every rank (HIP events)
+                              "streams_per_rank": counts,
+                              "root_expand_ms_standalone": expand_ms}
         # the bounds this kernel really sits under (it is not HBM-bound: SURVEY.md §8(d) consistency warning)
         rc = {"flops_per_column": FLOPS_PER_COLUMN.get(n), "flop_note": "SURVEY.md §8(d) algorithmic flops per column",
               "fp32_peak_tflops": FP32_PEAK_TFLOPS}
@@ -626,4 +672,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:      # any rank's failure ends the job with a non-zero exit (the launcher then stops the others)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

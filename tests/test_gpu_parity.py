@@ -703,10 +703,17 @@ def test_bench_two_rank_uneven_split_rehearsal():
         if check == "trials":
             trials = b["gather"]["split_trials"]
             assert len(trials) == 5 and all(sum(t["streams_per_rank"]) == 64 and t["columns_per_s"] > 0 for t in trials)
+            assert len(b["gather"]["kernel_ms_per_rank"]) == 2 and min(b["gather"]["kernel_ms_per_rank"]) > 0
             assert counts in [t["streams_per_rank"] for t in trials]
             assert counts == max(trials, key=lambda t: t["columns_per_s"])["streams_per_rank"]
         else:
             assert counts == [20, 44] and b["gather"]["split_trials"] is None
+    # a spent trial budget: the remaining splits are skipped on every rank together and the modelled split is used
+    r = subprocess.run(base + ["--trial-budget-s", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert b["gather"]["split_trials"][-1]["streams_per_rank"] is None and sum(b["config"]["streams_per_rank"]) == 64
+    assert b["config"]["streams_per_rank"][0] < 32 and b["value"] > 0
 
 
 def test_bench_one_rank_with_process_group_rehearsal():
@@ -726,6 +733,20 @@ def test_bench_one_rank_with_process_group_rehearsal():
     b = json.loads(lines[0])
     assert b["n_gpus"] == 1 and b["gather"]["path"] == "lib" and b["gather"]["note"] is None
     assert 32 < b["gather"]["wire_bytes_per_column"] < 768 and b["value"] > 0
+    # what the first N > 1 run must show: the rank count RCCL itself reports, every rank's kernel time, the split, and what
+    # the root's expand costs
+    g = b["gather"]
+    assert g["rccl_world"] == 1 and g["streams_per_rank"] == [8] and len(g["kernel_ms_per_rank"]) == 1 and g["kernel_ms_per_rank"][0] > 0
+    assert g["root_expand_ms_standalone"] is not None and g["root_expand_ms_standalone"] >= 0 and g["root_keeps_images_packed"] is False
+    # ... and the packed-on-root form of the same run (EMSPEC_GATHER_PACKED: the root only receives)
+    r = subprocess.run(cmd + ["--gather-packed"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29541"), cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    p = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert p["gather"]["root_keeps_images_packed"] is True and 32 < p["gather"]["wire_bytes_per_column"] < 768 and p["value"] > 0
+    # a failing rank ends the job with a non-zero exit
+    r = subprocess.run(cmd[:2] + ["--gather", "dist-loopback", "--streams", "2", "--log2-samples", "11", "--no-cpu-baseline", "--no-configs"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29543"), cwd=root)
+    assert r.returncode != 0
 
 
 def test_bench_device_synth_matches_definition():
