@@ -37,6 +37,14 @@ SIMDS = 256 * 4
 FLOPS_PER_COLUMN = {1024: 0.10e6, 2048: 0.21e6, 4096: 0.45e6, 8192: 0.93e6, 16384: 1.9e6}
 
 
+def executed_flops_per_column(n, rows=1024):
+    """What the kernels really execute per column: ONE packed complex FFT (N/2 log2 N radix-2 butterflies of 10 flops:
+    complex add, complex subtract, complex multiply as 2 mul + 2 fma) + the per-bin stage (N/2 bins x ~60 flops: stencils,
+    three dot products, reciprocal, index arithmetic) + dB (rows x ~8) - not the 1.5 FFTs of the three-window formulation."""
+    l2 = n.bit_length() - 1
+    return 10.0 * (n // 2) * l2 + 60.0 * (n // 2) + 8.0 * rows
+
+
 def sources_sha():
     """sha1 over the kernel / C-ABI sources: profile-derived numbers are only quoted when they were taken on these."""
     h = hashlib.sha1()
@@ -137,7 +145,7 @@ def host_cores():
 _HOST_CORES = host_cores()      # before anything loads an OpenMP runtime that might re-bind this thread
 
 
-def cpu_baseline(n, hop, seconds_target=8.0):
+def cpu_baseline(n, hop, seconds_target=3.0):
     """Time the CPU port of the same pipeline (oracle/emspec_cpu_fast.c: Stockham radix-4 FFT, ring histogram per
     stream, vectorised dB; gcc -O3 -march=native, OpenMP proc_bind(close)) on a bounded sample of the same workload:
     one thread, then one thread per physical core.  A stand-in ("port"): the reference's CPU path is private."""
@@ -152,17 +160,24 @@ def cpu_baseline(n, hop, seconds_target=8.0):
     rate1 = 256 / dt
     c1 = int(max(512, min(1 << 16, rate1 * seconds_target / 3)))
     base = synth.streams(1, n + hop * (c1 - 1))
-    t0 = time.perf_counter(); O.fast_batch(cfg, base, threads=1); dt1 = time.perf_counter() - t0
+    runs1 = []
+    for _ in range(3):          # wall-clock over >= 3 runs, median
+        t0 = time.perf_counter(); O.fast_batch(cfg, base, threads=1); runs1.append(time.perf_counter() - t0)
+    dt1 = float(np.median(runs1))
     per_core = c1 / dt1
     # all cores: one stream per core, each the same length (rolled copies: same statistics, distinct data)
     ca = int(max(512, min(c1, per_core * seconds_target * 2 / 3)))
     La = n + hop * (ca - 1)
     pcm = np.stack([np.roll(base[0, :La], 977 * s) for s in range(cores)])
-    t0 = time.perf_counter(); O.fast_batch(cfg, pcm, threads=cores); dta = time.perf_counter() - t0
-    return {"value": cores * ca / dta, "unit": "columns/s", "cores": cores, "kind": "port",
+    runsa = []
+    for _ in range(3):
+        t0 = time.perf_counter(); O.fast_batch(cfg, pcm, threads=cores); runsa.append(time.perf_counter() - t0)
+    dta = float(np.median(runsa))
+    return {"value": cores * ca / dta, "runs": 3, "statistic": "median",
+            "all_core_runs_s": runsa, "one_thread_runs_s": runs1, "unit": "columns/s", "cores": cores, "kind": "port",
             "per_core": per_core, "host_physical_cores": phys, "host_logical_cpus": logical,
-            "sample": f"{cores} streams x {ca} columns on {cores} threads (one per core, OpenMP proc_bind(close); the box's CPU quota) ({dta:.1f} s); one thread: {c1} "
-                      f"columns ({dt1:.1f} s).  N={n}, hop={hop}, reassign on, float32 dB + palette index out; "
+            "sample": f"{cores} streams x {ca} columns on {cores} threads (one per core, OpenMP proc_bind(close); the box's CPU quota) (median of 3 runs: {dta:.1f} s); one thread: {c1} "
+                      f"columns (median of 3: {dt1:.1f} s).  N={n}, hop={hop}, reassign on, float32 dB + palette index out; "
                       f"oracle/emspec_cpu_fast.c (same pipeline as the HIP kernels, Stockham radix-4 FFT, -O3 -march=native)"}
 
 
@@ -568,11 +583,16 @@ def main():
                               "streams_per_rank": counts,
                               "root_expand_ms_standalone": expand_ms}
         # the bounds this kernel really sits under (it is not HBM-bound: SURVEY.md §8(d) consistency warning)
-        rc = {"flops_per_column": FLOPS_PER_COLUMN.get(n), "flop_note": "SURVEY.md §8(d) algorithmic flops per column",
+        rc = {"flops_per_column": FLOPS_PER_COLUMN.get(n),
+              "flop_note": "flops_per_column / flop_frac are ALGORITHMIC-EQUIVALENT (SURVEY.md §8(d): the three-window formulation, 1.5 FFTs); "
+                           "executed_* count what the kernel really does (one packed FFT + spectral stencils)",
               "fp32_peak_tflops": FP32_PEAK_TFLOPS}
         if rc["flops_per_column"]:
             tf = rc["flops_per_column"] * (S * C) / (k_avg_ms * 1e-3) / 1e12
             rc["achieved_tflops"], rc["flop_frac"] = tf, tf / FP32_PEAK_TFLOPS
+            rc["executed_flops_per_column"] = executed_flops_per_column(n, R)
+            xtf = rc["executed_flops_per_column"] * (S * C) / (k_avg_ms * 1e-3) / 1e12
+            rc["executed_tflops"], rc["executed_flop_frac"] = xtf, xtf / FP32_PEAK_TFLOPS
         if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
             # cycle domain: a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md), so the VALU
             # pipes of 1024 SIMDs offer clock/2 wave-instructions per second each

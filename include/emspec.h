@@ -54,7 +54,7 @@ typedef enum emspec_status {
 
 /*
  * Engine configuration: the display-side settings the reference exposes as
- * sliders (README.md:44-51, assets/settings.png) plus the analysis grid.
+ * sliders (README.md:43-51, assets/settings.png) plus the analysis grid.
  * All fields are plain scalars; zero-initialise then call
  * emspec_default_config().
  */
@@ -66,10 +66,10 @@ typedef struct emspec_config {
     float sample_rate;     /* Hz, default 48000 */
     float fmin_hz;         /* lowest row edge, default 20 */
     float fmax_hz;         /* highest row edge, default sample_rate/2 */
-    float gain;            /* linear amplitude gain before dB ("Gain", README.md:46) */
+    float gain;            /* linear amplitude gain before dB ("Gain", README.md:47) */
     float db_top;          /* dB value mapped to palette index 255, default 0 */
-    float db_range;        /* dB span mapped onto the palette ("dB Range", README.md:45) */
-    float gate_db;         /* cells below this dB are drawn as index 0 ("Noise Gate", README.md:47) */
+    float db_range;        /* dB span mapped onto the palette ("dB Range", README.md:46) */
+    float gate_db;         /* cells below this dB are drawn as index 0 ("Noise Gate", README.md:51) */
     float power_floor;     /* bins with |X_h|^2 below this are not reassigned/accumulated */
 } emspec_config;
 

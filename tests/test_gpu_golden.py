@@ -25,6 +25,11 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
+# float32-vs-float64 (row, column) mismatch rates measured on the committed vectors, x 2
+# (measured r03: n1024_h256 3.34e-4 / 0; n1024_h256_off 0 / 0; n16384_h512 0 / 4.43e-4; n4096_h256 0 / 0; a zero gets room for one bin of the vector)
+GOLDEN_BOUNDS = {"n1024_h256": (6.7e-4, 3.4e-4), "n1024_h256_off": (3.4e-4, 3.4e-4), "n16384_h512": (6.4e-5, 8.9e-4), "n4096_h256": (1.3e-4, 1.3e-4)}
+
+
 def test_golden_vectors_exist():
     assert len(GOLD) >= 4
 
@@ -33,7 +38,7 @@ def test_golden_vectors_exist():
 def test_hip_dump_matches_golden(engine, path, record_property):
     """HIP per-bin dump vs the golden float64 vectors: power within 1e-4 (relative) on every bin within 60 dB of its
     frame's maximum; integer (column,row) equal except for bins whose continuous coordinate sits on a cell edge - the
-    measured mismatch rate is asserted (< 2e-3) and recorded."""
+    measured mismatch rate is asserted (<= 2x the rate measured on these vectors, GOLDEN_BOUNDS) and recorded."""
     g = np.load(path)
     n, hop, f0, fr, re = int(g["n"]), int(g["hop"]), int(g["frame0"]), int(g["frames"]), bool(g["reassign"])
     pw, col, row = engine.parity_dump(g["pcm"], n, hop, re, f0, fr)
@@ -49,7 +54,9 @@ def test_hip_dump_matches_golden(engine, path, record_property):
     record_property("col_mismatch_rate_vs_float64", col_rate)
     print(f"{os.path.basename(path)}: max rel power err (strong bins) {rel[strong].max():.2e}, "
           f"row mismatch {row_rate:.2e}, col mismatch {col_rate:.2e} of {int(valid.sum())} bins")
-    assert row_rate < 2e-3 and col_rate < 2e-3
+    print(f"MEASURED golden {os.path.basename(path)[:-4]}: row {row_rate:.3e} col {col_rate:.3e}")
+    rb, cb = GOLDEN_BOUNDS[os.path.basename(path)[:-4]]     # 2 x measured on these fixed vectors
+    assert row_rate <= rb and col_rate <= cb, (row_rate, col_rate)
     # and the bit model says exactly what the HIP path says (the golden pins the oracle, the oracle pins the kernels)
     opw, ocol, orow = O.frames_f32(O.make_cfg(n, hop, re), g["pcm"], f0, fr)
     assert np.array_equal(col, ocol) and np.array_equal(row, orow) and np.array_equal(pw, opw)
@@ -108,14 +115,19 @@ def test_push_samples_matches_oracle(n, hop, reassign, block):
     assert np.max(np.abs(got - odb[0])) < 8.7e-4
 
 
+# measured r03: 4096: 100 % / 1.05e-6 dB; 16384: 99.7845 % / 1.68e-6 dB; 1024: 100 % / 1.04e-6 dB -> disagreeing share and median x 2
+COLUMN_BOUNDS = {4096: (0.9995, 2.2e-6), 16384: (0.9956, 3.4e-6), 1024: (0.9995, 2.2e-6)}
+
+
 @pytest.mark.parametrize("n,hop", [(4096, 256), (16384, 512), (1024, 256)])
 def test_finished_columns_vs_float64_three_window(engine, n, hop, record_property):
     """Finished dB columns of the HIP path against the float64 textbook method (three explicitly windowed DFTs,
     float64 reassignment, float64 indices, float64 scatter and dB): the independent end-to-end check.
     float32 and float64 legitimately disagree on a bin whose coordinate sits on a cell edge (that bin's energy then
     lands in the neighbouring cell), and cells near the -80 dB display floor carry float32 FFT rounding noise.  Bound
-    asserted: among cells the float64 method puts above -60 dB, >= 99 % agree within 0.01 dB and the median error is
-    < 1e-4 dB; the rates are recorded."""
+    asserted: among cells the float64 method puts above -60 dB, the share that disagrees by more than 0.01 dB and the
+    median error stay within 2x what was measured (COLUMN_BOUNDS); the rates are recorded.  (The EXACT mode closes this
+    gap: tests/test_gpu_exact.py.)"""
     frames = 48
     pcm = synth.streams(1, n + hop * (frames - 1))
     cfg = O.make_cfg(n, hop, True)
@@ -135,7 +147,9 @@ def test_finished_columns_vs_float64_three_window(engine, n, hop, record_propert
     record_property("median_abs_err_dB", med)
     print(f"N={n}: {int(strong.sum())} cells above -60 dB, {agree:.4%} within 0.01 dB of float64, median |err| {med:.2e} dB, "
           f"max {err[strong].max():.3f} dB")
-    assert agree > 0.99 and med < 1e-4
+    print(f"MEASURED columns_vs_float64 N={n}: agree {agree:.6f} median {med:.3e}")
+    amin, mmax = COLUMN_BOUNDS[n]      # disagreeing share and median error: 2 x measured
+    assert agree >= amin and med <= mmax, (agree, med)
 
 
 @pytest.mark.parametrize("boost,zoom", [(1.5, 1.0), (2.0, 1.6)])

@@ -17,6 +17,11 @@ pytestmark = pytest.mark.gpu
 CASES = [(1024, 256), (4096, 256), (16384, 512), (2048, 128), (8192, 1024), (256, 64), (512, 512)]
 
 
+# measured float32-vs-float64 index mismatch rates of test_dump_vs_float64_oracle (row, column), x 2
+# (measured r03: 1024: 0 / 0 of 3,946 bins; 4096: 0 / 5.66e-4 of 15,912; 16384: 1.57e-5 / 2.20e-4 of 63,675; a zero is given room for one bin)
+F64_DUMP_BOUNDS = {1024: (2.6e-4, 2.6e-4), 4096: (6.3e-5, 1.14e-3), 16384: (3.2e-5, 4.4e-4)}
+
+
 def _pcm(n, hop, frames, S=2):
     return synth.streams(S, n + hop * (frames - 1) + 37)
 
@@ -49,8 +54,11 @@ def test_dump_vs_float64_oracle(engine, n, hop):
     # float32 vs float64 may legitimately disagree on a bin whose continuous
     # coordinate sits on a cell edge; it must be rare
     valid = r64 >= 0
-    assert np.mean(row[0][valid] != r64[valid]) < 2e-3
-    assert np.mean(col[0][valid] != c64[valid]) < 2e-3
+    rr, cr = float(np.mean(row[0][valid] != r64[valid])), float(np.mean(col[0][valid] != c64[valid]))
+    print(f"MEASURED dump_vs_float64 N={n}: row mismatch {rr:.3e}, col mismatch {cr:.3e} of {int(valid.sum())} bins")
+    # bounds = 2 x the rates measured on this (deterministic) input, so that drift is caught
+    rb, cb = F64_DUMP_BOUNDS[n]
+    assert rr <= rb and cr <= cb, (rr, cr)
 
 
 def test_tables_match_oracle(engine):
@@ -534,6 +542,10 @@ def test_generic_path_at_4096_with_many_rows(rows):
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
 
 
+# measured r03 (landing / row / column): 4096: 0 / 0 / 4.09e-4 of 31,757 bins; 16384: 0 / 7.86e-6 / 2.28e-4 of 127,261: x 2, a zero gets room for one bin
+HIPFFT_BOUNDS = {4096: (3.2e-5, 3.2e-5, 8.2e-4), 16384: (7.9e-6, 1.6e-5, 4.6e-4)}
+
+
 @pytest.mark.parametrize("n,hop", [(4096, 256), (16384, 512)])
 def test_dump_vs_hipfft_three_window(engine, n, hop):
     """an on-device cross-check that shares nothing with the hand-written
@@ -566,10 +578,11 @@ def test_dump_vs_hipfft_three_window(engine, n, hop):
     hrow = np.searchsorted(eb.astype(np.float64), khat, side="right") - 1
     hcol = np.arange(frames)[:, None] + cf
     # both sides must agree on which bins land at all, up to rare edge cases
-    assert np.mean((row[0] >= 0) != valid) < 2e-3
     both = valid & (row[0] >= 0)
-    assert np.mean(row[0][both] != hrow[both]) < 2e-3
-    assert np.mean(col[0][both] != hcol[both]) < 2e-3
+    lr, rr, cr = float(np.mean((row[0] >= 0) != valid)), float(np.mean(row[0][both] != hrow[both])), float(np.mean(col[0][both] != hcol[both]))
+    print(f"MEASURED dump_vs_hipfft N={n}: landing mismatch {lr:.3e}, row {rr:.3e}, col {cr:.3e} of {int(both.sum())} bins")
+    lb, rb, cb = HIPFFT_BOUNDS[n]      # 2 x measured
+    assert lr <= lb and rr <= rb and cr <= cb, (lr, rr, cr)
 
 
 @pytest.mark.parametrize("n,hop,reassign", [(4096, 256, True), (1024, 256, False), (2048, 2048, True), (16384, 512, True),
