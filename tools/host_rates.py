@@ -50,6 +50,43 @@ for j in range(20, 520):
 dt = (time.perf_counter() - t0) / 500
 print(f"emspec_column (streaming, one frame per call: one launch reading and writing page-locked host memory + sync): {dt * 1e6:.1f} us per column "
       f"= {1 / dt:.0f} columns/s per engine (real time needs 187.5/s per stream)")
+# where the per-call time goes: (a) the same call through raw ctypes with preallocated arrays (no numpy allocation, no
+# wrapper), (b) the fixed cost of one launch + one stream synchronisation, read off the smallest frame (N = 256: the kernel
+# itself is ~2 us), (c) the EXACT mode's call (two launches + copies)
+import ctypes as C_
+lib = emspec.load()
+dbo = np.empty(e.rows, np.float32)
+col = C_.c_int64(0)
+def raw(eng, frame, nn, hh):
+    return lib.emspec_column(eng._h, C_.c_void_p(frame.ctypes.data), nn, hh, 1, C_.c_void_p(dbo.ctypes.data), None, eng.rows, C_.byref(col))
+e.reset()
+frames = [np.ascontiguousarray(fr[j * hop:j * hop + n]) for j in range(520)]
+for j in range(20):
+    raw(e, frames[j], n, hop)
+t0 = time.perf_counter()
+for j in range(20, 520):
+    raw(e, frames[j], n, hop)
+dt_raw = (time.perf_counter() - t0) / 500
+e.reset()
+small = [np.ascontiguousarray(fr[j * 64:j * 64 + 256]) for j in range(520)]
+for j in range(20):
+    raw(e, small[j], 256, 64)
+t0 = time.perf_counter()
+for j in range(20, 520):
+    raw(e, small[j], 256, 64)
+dt_small = (time.perf_counter() - t0) / 500
+print(f"emspec_column through raw ctypes (no wrapper allocations): {dt_raw * 1e6:.1f} us per column at N = 4096; {dt_small * 1e6:.1f} us at N = 256 "
+      f"(= the fixed cost of one launch + one stream synchronisation + the two host copies; a hipGraph replay costs 10-16 us "
+      f"on this stack against 3-5 us for a direct launch - MI355X_MICROARCH.md 'graph-replay-floor' - so capturing this single "
+      f"launch cannot lower it)")
+with emspec.Engine(mode=emspec.MODE_EXACT) as x:
+    for j in range(20):
+        raw(x, frames[j], n, hop)
+    t0 = time.perf_counter()
+    for j in range(20, 520):
+        raw(x, frames[j], n, hop)
+    dt_x = (time.perf_counter() - t0) / 500
+print(f"emspec_column, EXACT mode (binary64, u64 ring; frame copy + two launches + column copy): {dt_x * 1e6:.1f} us per column")
 for blk in (128, 512, 2048, 16384, 131072):
     e.reset()
     e.push_samples(fr[:n + 16 * hop], n, hop, True)
