@@ -618,7 +618,8 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     // the generic path shares one record workspace, so it stays on one stream too
     // ... and so does the display post-process (raw dB / peak / post workspaces are per engine, not per lane)
     const bool display = e->smoothing > 0.0f || e->agc > 0.0f;
-    const bool two = pinned && fused_supported(n, hop, e->cfg.rows, reassign) && S > 1 && !display;
+    // ... and the EXACT mode (one record workspace per engine)
+    const bool two = pinned && !e->exact() && fused_supported(n, hop, e->cfg.rows, reassign) && S > 1 && !display;
     if (two && !e->stream2 && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
         unpin();
         return fail(e, EMSPEC_ERR_HIP, "hipStreamCreate failed");

@@ -201,6 +201,22 @@ def test_exact_custom_axis_and_settings(xengine):
             O.set_custom_edges_hz(None)
 
 
+def test_exact_batch_from_pinned_buffers(xengine):
+    """Host-buffer batch from page-locked memory (the fast mode pipelines stream chunks on two HIP streams there; the
+    exact mode has one record workspace per engine and must not): > 96 MB of staging, bytes equal to the bit model."""
+    n, hop, S = 4096, 256, 6
+    L = n + hop * 1500
+    pcm = synth.streams(S, L)
+    pin = emspec.PinnedArray(pcm.shape, np.float32)
+    pin.array[...] = pcm
+    Cn = emspec.num_columns(L, n, hop)
+    pout = emspec.PinnedArray((S, Cn, xengine.rows), np.float32)
+    out = xengine.batch(pin.array, n, hop, True, want=("db",), db_out=pout.array)["db"]
+    odb, _, _, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db",))
+    assert np.array_equal(out.view(np.uint32), odb.view(np.uint32))
+    pin.close(); pout.close()
+
+
 def test_exact_mode_guards(xengine, engine):
     pcm = _pcm(1024, 256, 4, S=1)
     with pytest.raises(emspec.EmspecError) as ei:
