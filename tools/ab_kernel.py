@@ -15,8 +15,8 @@ emspec.LIB_PATH = %(lib)r
 from bench import synth_device, time_launches
 n, hop = %(n)d, %(hop)d
 dev = torch.device("cuda", 0)
-eng = emspec.Engine()
-S, L = 64, 1 << 22
+eng = emspec.Engine(mode=emspec.MODE_EXACT if %(exact)d else emspec.MODE_FAST)
+S, L = (16 if %(exact)d else 64), 1 << 22
 C = emspec.num_columns(L, n, hop)
 pcm = synth_device(S, L, 0, dev)
 db = torch.empty((S, C, eng.rows), dtype=torch.float32, device=dev)
@@ -50,6 +50,7 @@ ap.add_argument("--workload", default="batch64")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--n", type=int, default=0, help="FFT size (overrides --workload)")
 ap.add_argument("--hop", type=int, default=0)
+ap.add_argument("--exact", action="store_true", help="EXACT mode engine, 16 streams")
 ap.add_argument("--dump", action="store_true", help="time the per-bin parity dump (16 streams x 2^20 samples) instead of the batch")
 a = ap.parse_args()
 n, hop, reps = (16384, 512, 4) if a.workload == "n16384" else (4096, 256, 8)
@@ -58,7 +59,7 @@ if a.n:
 res = {l: [] for l in a.libs}
 for r in range(a.rounds):
     for lib in a.libs:
-        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps, dump=int(a.dump))],
+        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps, dump=int(a.dump), exact=int(a.exact))],
                              capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             sys.exit(out.stderr[-2000:])
