@@ -384,11 +384,12 @@ def main():
             chunk = lambda Sx: [(Sx * i // nch, Sx * (i + 1) // nch) for i in range(nch)]     # the same rule on every rank
             self.bounds = chunk(Sl)
             self.gathered = None
+            self.packed = bool(args.gather_packed and gather_mode == "lib")
+            self.per_rank = [chunk(c) for c in counts]
             if gathering and rank == 0:
-                per_rank = [chunk(c) for c in counts]
-                if gather_mode == "lib" and args.gather_packed:   # [chunk] -> directory + the ranks' packed images
-                    self.gathered = [torch.empty((256 * (world + 1) + sum(emspec.wire_bound((pr[ci][1] - pr[ci][0]) * C, R) for pr in per_rank),),
-                                                 dtype=torch.uint8, device=dev) for ci in range(nch)]
+                per_rank = self.per_rank
+                if self.packed:               # [chunk] -> directory + the ranks' packed images
+                    self.gathered = self.packed_buffers()
                 elif gather_mode == "lib":    # [chunk] -> the ranks' blocks [streams of the chunk, C, R] one after the other
                     self.gathered = [torch.empty((sum(pr[ci][1] - pr[ci][0] for pr in per_rank), C, R), dtype=torch.uint8, device=dev)
                                      for ci in range(nch)]
@@ -401,6 +402,19 @@ def main():
             self.wire_bytes = [0, 0]                            # packed bytes this rank sent, columns they carried
             self.kev = []
 
+        def packed_buffers(self):
+            return [torch.empty((256 * (world + 1) + sum(emspec.wire_bound((pr[ci][1] - pr[ci][0]) * C, R) for pr in self.per_rank),),
+                                dtype=torch.uint8, device=dev) for ci in range(self.nch)]
+
+        def switch_to_packed(self):
+            """keep the root's images packed from now on (EMSPEC_GATHER_PACKED): the root only receives"""
+            self.flush()
+            torch.cuda.synchronize(dev)
+            self.packed = True
+            if rank == 0:
+                self.gathered = None
+                self.gathered = self.packed_buffers()
+
         def do_gather(self, p, ci, ready):
             a, b = self.bounds[ci]
             ibuf = self.idx_bufs[p]
@@ -410,7 +424,7 @@ def main():
                     # pack + size exchange + send/recv + expand on comm_stream; the call synchronises comm_stream once, while
                     # the next chunk's kernels (already enqueued on the compute stream) keep the GPU busy
                     nb = eng.gather_columns(ibuf[a:b], root=0, out=self.gathered[ci] if rank == 0 else None, stream=comm_stream,
-                                            loopback=(world == 1), packed=args.gather_packed)
+                                            loopback=(world == 1), packed=self.packed)
                     if rank != 0 or world == 1:     # (packed mode reports the root's own image size too: it is not sent)
                         self.wire_bytes[0] += nb
                         self.wire_bytes[1] += (b - a) * C if nb else 0
@@ -515,6 +529,13 @@ def main():
         wb = torch.tensor(wire_bytes, dtype=torch.float64, device=gdev)
         dist.all_reduce(wb, op=dist.ReduceOp.SUM)
         wire_bytes = [float(wb[0].item()), float(wb[1].item())]
+    # the same job with the images kept packed on the root (EMSPEC_GATHER_PACKED: nothing is lost, the root only receives and
+    # expands on demand): three more steps after the timed run, reported beside the headline, never as the headline
+    packed_cps = None
+    if gathering and gather_mode == "lib" and not args.gather_packed:     # (also in the one-GPU loopback rehearsals)
+        job.switch_to_packed()
+        job.run(1)
+        packed_cps = total_streams * C * 3 / job.run(3)
     S_nominal = S
     # every rank's own column-kernel time per step (HIP events on its launch stream), gathered for the line
     my_kms = float(np.mean([a.elapsed_time(b) for a, b in job.kev])) if job.kev else 0.0
@@ -579,6 +600,7 @@ def main():
                               "raw_bytes_per_column": R,
                               "rccl_world": eng.comm_world if gather_mode == "lib" else None,      # what RCCL itself reports
                               "root_keeps_images_packed": bool(args.gather_packed and gather_mode == "lib"),
+                              "packed_columns_per_s": packed_cps,     # the same split with EMSPEC_GATHER_PACKED (3 steps after the timed run)
                               "kernel_ms_per_rank": rank_kms,                 # column-kernel time per step on every rank (HIP events)
                               "streams_per_rank": counts,
                               "root_expand_ms_standalone": expand_ms}

@@ -751,6 +751,7 @@ def test_bench_one_rank_with_process_group_rehearsal():
     g = b["gather"]
     assert g["rccl_world"] == 1 and g["streams_per_rank"] == [8] and len(g["kernel_ms_per_rank"]) == 1 and g["kernel_ms_per_rank"][0] > 0
     assert g["root_expand_ms_standalone"] is not None and g["root_expand_ms_standalone"] >= 0 and g["root_keeps_images_packed"] is False
+    assert g["packed_columns_per_s"] > 0        # the same job with the images kept packed on the root, measured after the timed run
     # ... and the packed-on-root form of the same run (EMSPEC_GATHER_PACKED: the root only receives)
     r = subprocess.run(cmd + ["--gather-packed"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29541"), cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
