@@ -47,6 +47,7 @@ struct ExactSinks {
     int64_t total_cols = 0;
     int32_t ring = 0;
     int64_t col_offset = 0;
+    int32_t edges_lds = 1;     // set by the launcher: the binary64 edge table is staged in LDS (0: read from global memory)
 };
 hipError_t launch_exact_frames(int n, const ExactPlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
                                int64_t nframes, const ExactSinks& sinks, hipStream_t st);

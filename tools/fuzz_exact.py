@@ -19,7 +19,7 @@ t0 = time.time()
 for ci in range(cases):
     n = int(rng.choice([256, 512, 1024, 2048, 4096, 4096, 4096, 8192, 16384]))
     hop = int(rng.choice([n // 16, n // 16, n // 8, n // 4, n // 2, n, max(1, n // 32), int(rng.integers(1, n + 1))]))
-    rows = int(rng.choice([64, 128, 256, 512, 1024, 1024, 2048]))
+    rows = int(rng.choice([64, 68, 100, 128, 256, 512, 1000, 1024, 1024, 2048, 4096]))
     reassign = bool(rng.integers(0, 2))
     S = int(rng.integers(1, 4))
     D = -(-n // (2 * hop)) if reassign else 0
