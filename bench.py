@@ -669,6 +669,14 @@ def main():
                 cfgs[name] = {"columns_per_s": Sx * Cx / (ms * 1e-3), "columns_per_launch": Sx * Cx, "kernel_ms": ms,
                               "dtype": "f64", "roofline": roofline(Sx * Cx, 4 * hx + 5 * R, ms)}
             xeng.close()
+            if not args.no_cpu_baseline:
+                # the binary64 bit model (oracle/emspec_exact.c, scalar C, one thread) on a bounded sample: the CPU figure beside
+                # the EXACT mode's rate ("port": there is no reference CPU path to time)
+                import oracle as O
+                from emspec import synth as _synth
+                xs = _synth.streams(1, 4096 + 256 * 1023)
+                t0 = time.perf_counter(); O.batch_exact(O.make_cfg(4096, 256, True), xs, want=("db", "index"), threads=1); dtx = time.perf_counter() - t0
+                cfgs["EXACT mode, configs[2] shape: 16 streams, FFT 4096, hop 256, reassignment ON"]["cpu_port_columns_per_s_one_thread"] = 1024 / dtx
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
 
