@@ -67,7 +67,48 @@ int main(void) {
     CHECK(emspec_reset(e) == EMSPEC_OK, "reset");
     CHECK(emspec_column(e, pcm, 1024, hop, 0, col, NULL, R, &ci) == EMSPEC_OK && ci == 0, "reassign-off column has no latency");
     emspec_destroy(e);
+
+    /* EXACT mode through the same ABI (cfg.mode): the streaming call must give the batch call's BITS (64-bit fixed-point
+     * histogram: order-independent), two batch runs the same bytes, and the per-bin dump the fixed-point energies */
+    cfg.mode = EMSPEC_MODE_EXACT;
+    emspec_engine* x = NULL;
+    CHECK(emspec_create(&cfg, &x) == EMSPEC_OK, emspec_last_error(NULL));
+    float* xdb = (float*)malloc(sizeof(float) * frames * R);
+    float* xdb2 = (float*)malloc(sizeof(float) * frames * R);
+    emspec_out xo = {xdb, NULL, NULL}, xo2 = {xdb2, NULL, NULL};
+    CHECK(emspec_batch(x, pcm, 1, L, n, hop, 1, &xo) == EMSPEC_OK, emspec_last_error(x));
+    CHECK(emspec_batch(x, pcm, 1, L, n, hop, 1, &xo2) == EMSPEC_OK, emspec_last_error(x));
+    CHECK(memcmp(xdb, xdb2, sizeof(float) * frames * R) == 0, "exact mode: two runs differ");
+    double xworst = 0;
+    for (int i = 0; i < frames * R; ++i) if (db[i] > -60.0f) { double d = fabs(xdb[i] - db[i]); if (d > xworst) xworst = d; }
+    CHECK(xworst < 0.05, "exact and fast mode disagree on a strong cell");
+    for (int j = 0; j < frames; ++j) {
+        CHECK(emspec_column(x, pcm + (long)j * hop, n, hop, 1, col, NULL, R, &ci) == EMSPEC_OK, emspec_last_error(x));
+        if (j >= D) CHECK(memcmp(col, xdb + (size_t)(j - D) * R, sizeof(float) * R) == 0, "exact mode: streaming column differs from the batch bits");
+    }
+    for (int k = 0; k < D; ++k) {
+        CHECK(emspec_column_flush(x, col, NULL, R, &ci) == EMSPEC_OK, "flush");
+        CHECK(memcmp(col, xdb + (size_t)ci * R, sizeof(float) * R) == 0, "exact mode: flushed column differs from the batch bits");
+    }
+    {
+        const int K = n / 2 + 1;
+        double* pw = (double*)malloc(sizeof(double) * 2 * K);
+        int32_t* cc = (int32_t*)malloc(sizeof(int32_t) * 2 * K);
+        int32_t* rr = (int32_t*)malloc(sizeof(int32_t) * 2 * K);
+        int64_t* qq = (int64_t*)malloc(sizeof(int64_t) * 2 * K);
+        CHECK(emspec_parity_dump_exact(x, pcm, 1, L, n, hop, 1, 20, 2, pw, cc, rr, qq) == EMSPEC_OK, emspec_last_error(x));
+        int peak = 0;
+        for (int k = 1; k < K; ++k) if (pw[k] > pw[peak]) peak = k;
+        CHECK(abs(peak - 85) <= 1, "exact dump: the 1 kHz line is not at bin 85");        /* 1000 Hz * 4096 / 48000 = 85.3 */
+        CHECK(rr[peak] >= 0 && qq[peak] > 0, "exact dump: the peak bin was dropped");
+        CHECK(fabs((double)qq[peak] - pw[peak] * 4294967296.0) <= 0.5 + 1e-6 * (double)qq[peak], "exact dump: q is not round(power * 2^52 / (N/4)^2) = power * 2^32");
+        float fpw[8]; int32_t fc[8], frw[8];
+        CHECK(emspec_parity_dump(x, pcm, 1, L, n, hop, 1, 0, 1, fpw, fc, frw) == EMSPEC_ERR_STATE, "float32 dump accepted by an exact-mode engine");
+        free(pw); free(cc); free(rr); free(qq);
+    }
+    emspec_destroy(x);
+    free(xdb); free(xdb2);
     free(pcm); free(db); free(rgba); free(col);
-    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e\n", worst);
+    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells\n", worst, xworst);
     return 0;
 }
