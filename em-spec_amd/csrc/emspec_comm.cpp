@@ -45,8 +45,10 @@ struct emspec_comm_state {
     uint64_t* h_sizes = nullptr;                             // page-locked copy
     // layout of the last EMSPEC_GATHER_PACKED gather on the root: per rank (offset in gathered_dev, image bytes, columns)
     std::vector<uint64_t> packed_layout;
-    uint64_t* h_dir = nullptr;                               // page-locked directory, copied to the head of gathered_dev
+    uint64_t* h_dir = nullptr;                               // page-locked directories (kDirSlots of them, used in rotation: the
+    unsigned dir_next = 0;                                   //  copy to the head of gathered_dev is still in flight at return)
 };
+static constexpr unsigned kDirSlots = 8;
 
 namespace {
 
@@ -111,7 +113,7 @@ int emspec_comm_init(emspec_engine* e, const uint8_t* id_bytes, int32_t rank, in
     c->world = world;
     HIPCHK(e, hipMalloc(&c->d_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1)));
     HIPCHK(e, hipHostMalloc((void**)&c->h_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1), hipHostMallocDefault));
-    HIPCHK(e, hipHostMalloc((void**)&c->h_dir, sizeof(uint64_t) * 4 * (size_t)world + 64, hipHostMallocDefault));
+    HIPCHK(e, hipHostMalloc((void**)&c->h_dir, sizeof(uint64_t) * 4 * (size_t)world * kDirSlots + 64, hipHostMallocDefault));
     return EMSPEC_OK;
 }
 
@@ -256,13 +258,14 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
         // aligned, in rank order; the root's own image is a device copy of what it packed above.  Expand any of them
         // later with emspec_wire_unpack(gathered_dev + offset, bytes, columns, ...): emspec_gather_packed_layout.
         c->packed_layout.assign((size_t)world * 3, 0);
+        uint64_t* dir = c->h_dir + (size_t)(c->dir_next++ % kDirSlots) * 4 * (size_t)world;
         for (int r = 0; r < world; ++r) {
-            c->h_dir[4 * r] = c->packed_layout[3 * r] = (uint64_t)(dir_bytes + off[r]);
-            c->h_dir[4 * r + 1] = c->packed_layout[3 * r + 1] = c->h_sizes[2 * r];
-            c->h_dir[4 * r + 2] = c->packed_layout[3 * r + 2] = c->h_sizes[2 * r + 1];
-            c->h_dir[4 * r + 3] = 0;
+            dir[4 * r] = c->packed_layout[3 * r] = (uint64_t)(dir_bytes + off[r]);
+            dir[4 * r + 1] = c->packed_layout[3 * r + 1] = c->h_sizes[2 * r];
+            dir[4 * r + 2] = c->packed_layout[3 * r + 2] = c->h_sizes[2 * r + 1];
+            dir[4 * r + 3] = 0;
         }
-        HIPCHK(e, hipMemcpyAsync(gathered_dev, c->h_dir, sizeof(uint64_t) * 4 * (size_t)world, hipMemcpyHostToDevice, st));
+        HIPCHK(e, hipMemcpyAsync(gathered_dev, dir, sizeof(uint64_t) * 4 * (size_t)world, hipMemcpyHostToDevice, st));
         if (!loopback)
             HIPCHK(e, hipMemcpyAsync(gathered_dev + dir_bytes + off[me], c->d_wire, (size_t)c->h_sizes[2 * me], hipMemcpyDeviceToDevice, st));
         return EMSPEC_OK;

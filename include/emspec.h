@@ -351,8 +351,10 @@ int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twi
 
 /* 1 if emspec_batch/_device would run a fused LDS-ring kernel for this shape
  * (n = 1024, 2048, 4096 at any hop whose column ring fits in LDS; n = 8192 at
- * hop 512 or 1024; at most 1024 rows), 0 if the generic two-kernel path
- * (per-bin records + LDS tile scatter).  Same results either way. */
+ * hop 512 or 1024; n = 16384 at any hop whose ring has at most 33 slots of 1024
+ * rows, e.g. hop 512; at most 1024 rows), 0 if the generic two-kernel path
+ * (per-bin records + LDS tile / walking-ring scatter) - always 0 for an
+ * EXACT-mode engine.  Same results either way. */
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign);
 
 /* Name of the device the engine runs on, e.g. "gfx950". */
