@@ -306,3 +306,65 @@ def test_exact_batch_is_order_independent_fixed_point():
     db32, _, _ = O.batch_f32(cfg, pcm, want=("db",))
     loud = ref > -60.0
     assert np.mean(np.abs(db32 - db)[loud] < 1e-2) > 0.99
+
+
+@pytest.mark.parametrize("n,hop", [(1024, 256), (4096, 256), (16384, 512)])
+def test_power_against_scipy_stft(n, hop):
+    """An EXTERNAL implementation for the rows 'Frame gather', 'Windows', 'STFT', 'Power' of SURVEY.md §8(a): scipy.signal.stft
+    (periodic Hann, no padding) against |X_h|^2 of the float64 method, the binary64 bit model and - within float32 accuracy -
+    the float32 bit model.  (scipy has no reassignment; (t-hat, f-hat) stay pinned by the numpy formulation and the KATs.)"""
+    ss = pytest.importorskip("scipy.signal")
+    frames = 10
+    pcm = synth.stream(5, n + hop * (frames - 1))
+    w = ss.get_window("hann", n, fftbins=True)
+    _, _, Z = ss.stft(pcm.astype(np.float64), fs=FS, window=w, nperseg=n, noverlap=n - hop, boundary=None, padded=False,
+                      return_onesided=True, scaling="spectrum")
+    ref = ((np.abs(Z) * w.sum()) ** 2).T                      # [frames][K]
+    cfg = O.make_cfg(n, hop, True)
+    p64 = O.frames_f64(cfg, pcm, 0, frames)[0]
+    pex = O.frames_exact(cfg, pcm, 0, frames)[0]
+    p32 = O.frames_f32(cfg, pcm, 0, frames)[0]
+    strong = ref >= ref.max(axis=1, keepdims=True) * 1e-12
+    assert (np.abs(p64 - ref) / np.maximum(ref, 1e-300))[strong].max() < 1e-9
+    assert (np.abs(pex - ref) / np.maximum(ref, 1e-300))[strong].max() < 1e-9
+    strong32 = ref >= ref.max(axis=1, keepdims=True) * 1e-6
+    assert (np.abs(p32 - ref) / np.maximum(ref, 1e-300))[strong32].max() < 1e-4
+
+
+def test_reassignment_equals_phase_derivatives():
+    """north_star names the method by its definition: 'per-bin phase-derivative reassignment of energy to (t-hat, f-hat)'.
+    The three-window formulas the oracle (and the kernels) evaluate are the closed form of those derivatives; this test
+    evaluates the DEFINITION numerically - f-hat = (1/2pi) d(phase)/dt by a central difference of the Hann STFT over +-1
+    sample, t-hat = -d(phase)/d(omega) by a central difference on a 256x zero-padded frequency grid - and compares, using
+    nothing but numpy FFTs of Hann-windowed frames.  Signal: two sinusoids, a chirp and two clicks."""
+    n, hop, j = 4096, 256, 4
+    L = n + hop * 8 + 4
+    t = np.arange(L) / FS
+    x = 0.6 * np.cos(2 * np.pi * 1234.567 * t + 0.3) + 0.3 * np.cos(2 * np.pi * (3000 * t + 0.5 * 2.0e4 * t * t)) + \
+        0.2 * np.cos(2 * np.pi * 9876.5 * t)
+    x[3000] += 0.8
+    x[2100] += 0.5
+    x = x.astype(np.float32)
+    p = j * hop
+    h = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
+    cfg = O.make_cfg(n, hop, True)
+    p64, that, khat, c64, r64 = O.frames_f64(cfg, x, j, 1)
+    strong = p64[0] > p64[0].max() * 1e-4
+    k = np.arange(n // 2 + 1)
+    # instantaneous frequency: phase advance per sample at a fixed bin, unwrapped around the bin's own frequency
+    Xm = np.fft.rfft(x[p - 1:p - 1 + n].astype(np.float64) * h)
+    Xp = np.fft.rfft(x[p + 1:p + 1 + n].astype(np.float64) * h)
+    dphi = np.angle(Xp * np.conj(Xm) * np.exp(-1j * 4 * np.pi * k / n)) / 2 + 2 * np.pi * k / n
+    assert np.max(np.abs(khat[0] - dphi * n / (2 * np.pi))[strong]) < 1e-4          # bins (measured 2e-5)
+    # group delay: -d(phase)/d(omega) on a fine grid, time origin at the frame centre
+    Z = 256
+    Xf = np.fft.rfft(x[p:p + n].astype(np.float64) * h, Z * n)
+    Xr = Xf * np.exp(1j * np.pi * np.arange(Xf.size) / Z)
+    kk = np.arange(1, n // 2)
+    d = np.angle(Xr[Z * kk + 1] * np.conj(Xr[Z * kk - 1])) / 2
+    t_fd = p + n / 2 - d * (Z * n) / (2 * np.pi)
+    err = np.abs(that[0][1:n // 2] - t_fd)[strong[1:n // 2]]
+    assert err.max() < 0.5 and np.median(err) < 1e-3, (err.max(), np.median(err))   # samples (measured 0.13 / 7e-5; O(1/Z^2))
+    # and the exact mode's integer indices are the float64 method's on this frame
+    _, col, row, _ = O.frames_exact(cfg, x, j, 1)
+    assert np.array_equal(col, c64) and np.array_equal(row, r64)
