@@ -180,9 +180,10 @@ def test_exact_streaming_equals_batch_bytes(n, hop, reassign):
         assert np.array_equal(np.stack(cols).view(np.uint32), odb[0].view(np.uint32))
 
 
-def test_exact_custom_axis_and_settings(xengine):
-    """A warped frequency axis (emspec_set_row_edges_hz) and non-default display settings in EXACT mode."""
-    n, hop, frames = 4096, 256, 40
+@pytest.mark.parametrize("n,hop,frames", [(4096, 256, 40), (16384, 512, 40)])
+def test_exact_custom_axis_and_settings(xengine, n, hop, frames):
+    """A warped frequency axis (emspec_set_row_edges_hz; BASELINE configs[4]: 'FFT 16384 ... + low-end log-freq rebinning')
+    and non-default display settings in EXACT mode."""
     pcm = _pcm(n, hop, frames, S=1)
     edges = emspec.warped_edges_hz(1024, 20.0, 24000.0, 2.0, 1.6)
     with emspec.Engine(mode=emspec.MODE_EXACT, gain=3.5, db_range=58.0, gate_db=-65.0) as e:
