@@ -172,8 +172,18 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     const int64_t total = (int64_t)gridDim.x * gridDim.y, lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int64_t full = total & ~(int64_t)7;
     const int64_t work = lin < full ? (lin & 7) * (full >> 3) + (lin >> 3) : lin;
-    const int64_t f = work % gridDim.x;    // frame within the launch
-    const int s = (int)(work / gridDim.x); // stream
+    // (32-bit division whenever the launch has fewer than 2^32 workgroups, i.e. always in practice: a 64-bit division or
+    // modulo is ~140 scalar instructions on this hardware, and every workgroup - one frame - paid two of them)
+    int64_t f;                             // frame within the launch
+    int s;                                 // stream
+    if (total <= 0xFFFFFFFFll) {
+        const unsigned w32 = (unsigned)work, q32 = w32 / gridDim.x;
+        s = (int)q32;
+        f = (int64_t)(w32 - q32 * gridDim.x);
+    } else {
+        f = work % gridDim.x;
+        s = (int)(work / gridDim.x);
+    }
     const int64_t j = frame0 + f;          // frame within the pcm buffer
     const int64_t jcol = j + sk.col_offset; // its own absolute column
 
