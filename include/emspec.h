@@ -84,7 +84,7 @@ typedef struct emspec_config {
  *                      with a float64 implementation of the three-window method on every bin, and dB / palette index /
  *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes.  Inputs must stay
  *                      within |x| <= 4 (the fixed point covers 2^11 full-scale-sine powers per cell).  Same entry points;
- *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 3.6x slower than the fast mode at N = 4096.
+ *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 3.2x slower than the fast mode at N = 4096.
  */
 #define EMSPEC_MODE_FAST 0
 #define EMSPEC_MODE_EXACT 1
