@@ -243,3 +243,22 @@ def test_exact_silence_and_extremes(xengine):
     assert np.isfinite(out["db"]).all()
     assert np.array_equal(out["index"], oidx) and np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
     assert out["index"][0].max() == 0
+
+
+def test_exact_nan_and_inf_samples(xengine):
+    """A NaN and an Inf sample poison the frames that contain them (every bin of such a frame fails the power gate and is
+    dropped); the other frames are untouched, the output stays finite and equal to the bit model's."""
+    n, hop, frames = 4096, 256, 48
+    pcm = synth.streams(2, n + hop * (frames - 1))
+    pcm[0, 5000] = np.nan
+    pcm[1, 9000] = np.inf
+    out = xengine.batch(pcm, n, hop, True, want=("db", "index"))
+    odb, _, oidx, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.isfinite(out["db"]).all()
+    assert np.array_equal(out["index"], oidx) and np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
+    pw, col, row, q = xengine.parity_dump_exact(pcm, n, hop, True, 0, frames)
+    opw, ocol, orow, oq = O.frames_exact(O.make_cfg(n, hop, True), pcm[0], 0, frames)
+    assert np.array_equal(row[0], orow) and np.array_equal(col[0], ocol) and np.array_equal(q[0], oq)
+    assert np.array_equal(pw[0], opw, equal_nan=True)
+    poisoned = [j for j in range(frames) if j * hop <= 5000 < j * hop + n]
+    assert poisoned and np.all(row[0][poisoned] == -1) and np.all(q[0][poisoned] == 0)
