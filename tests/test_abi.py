@@ -42,7 +42,7 @@ def test_diag_library_adds_only_the_debug_header():
     assert "emspec_debug_row_lookup" in dbg and "emspec_debug_phase_cycles" in dbg and "emspec_debug_recip" in dbg
     assert exported_functions(emspec.DIAG_LIB_PATH) == sorted(set(declared_functions("emspec.h")) | set(dbg))
     out = subprocess.run(["strings", "-n", "6", emspec.LIB_PATH], capture_output=True, text=True).stdout
-    for needle in ("EMSPEC_FUSED_VARIANT", "EMSPEC_NO_FUSED", "EMSPEC_SEGLEN", "EMSPEC_NO_WALK", "fused4096_r8t", "fused4096_pp", "occupy_kernel"):
+    for needle in ("EMSPEC_FUSED_VARIANT", "EMSPEC_NO_FUSED", "EMSPEC_SEGLEN", "EMSPEC_NO_WALK", "fused4096_r8t", "fused4096_r8_kernel", "occupy_kernel"):
         assert needle not in out, f"{needle} is diagnostic and must not be in libemspec.so"
 
 
@@ -123,7 +123,7 @@ def test_flagship_kernels_do_not_spill():
     seen = 0
     for m in re.finditer(r"\.name:\s+(\S+)\n", text):
         name = m.group(1)
-        if not any(k in name for k in ("fused4096_r8_kernelILi256ELb0", "fused4096_r8_kernelILi512ELb0", "fused8192_kernel",
+        if not any(k in name for k in ("fused4096_pp_kernelILi256ELb0", "fused4096_pp_kernelILi512ELb0", "fused8192_kernel",
                                        "fused_small_kernel")):
             continue
         blk = text[m.start() - 400:m.start() + 1600]
