@@ -2,6 +2,7 @@
 """A/B two builds of libemspec.so on the same box: alternates them (child process each), times the column kernel of a
 bench workload with HIP events, prints ms per launch.  Box-to-box spread is ~2 %, so variants are compared here.
    python tools/ab_kernel.py libA.so libB.so [--workload batch64|n16384] [--rounds 3]
+A library given as path@VARIANT runs with EMSPEC_FUSED_VARIANT=VARIANT (libemspec_diag.so only).
 """
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,8 +60,10 @@ if a.n:
 res = {l: [] for l in a.libs}
 for r in range(a.rounds):
     for lib in a.libs:
-        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(lib), n=n, hop=hop, reps=reps, dump=int(a.dump), exact=int(a.exact))],
-                             capture_output=True, text=True, timeout=300)
+        path, _, variant = lib.partition("@")
+        env = dict(os.environ, EMSPEC_FUSED_VARIANT=variant) if variant else None
+        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(path), n=n, hop=hop, reps=reps, dump=int(a.dump), exact=int(a.exact))],
+                             capture_output=True, text=True, timeout=300, env=env)
         if out.returncode != 0:
             sys.exit(out.stderr[-2000:])
         res[lib].append(float(out.stdout.strip().splitlines()[-1]))

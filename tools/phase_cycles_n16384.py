@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 for _ in range(2):
     assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
-names = ["load+pass1+write", "barrier wait", "mid passes+last+rewrite", "bins", "ring out", "scatter", "finalize+ring in", "-"]
+names = ["pass-1 write", "barrier wait", "mid passes+last+rewrite", "bins", "ring out+prefetch", "scatter+next pass 1", "finalize+ring in", "-"]
 frames = Cn / (groups.value / S) + 32
 tot = cyc[:, :, :7].sum(axis=2).astype(np.float64)    # slot 7: 100 MHz ticks of the walk (high word), not a phase
 print(f"groups {groups.value}, {frames:.0f} frames each; mean cycles per wave per frame {tot.mean() / frames:.0f}")
