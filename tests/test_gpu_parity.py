@@ -463,6 +463,50 @@ def test_no_spin_timeouts(diag_engine):
     assert lib.emspec_debug_fused_error(engine._h) == 0
 
 
+_VARIANT_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "em-spec_amd")]
+import emspec
+from emspec import synth
+pcm = synth.streams(3, 4096 + 256 * 1499)
+with emspec.Engine(diag=%(diag)r) as e:
+    out = e.batch(pcm, 4096, 256, True, want=("db", "index"))
+    if %(diag)r:
+        import ctypes as C
+        lib = emspec.load(diag=True)
+        lib.emspec_debug_fused_error.argtypes = [C.c_void_p]
+        assert lib.emspec_debug_fused_error(e._h) == 0, "a bounded spin timed out"
+np.savez(sys.argv[1], db=out["db"], index=out["index"])
+"""
+
+
+@pytest.mark.parametrize("variant", ["r8", "ppt", "r8t", "r16"])
+def test_fused_ab_variants_match_the_product(variant, tmp_path):
+    """The A/B variants of the N = 4096 kernel kept in libemspec_diag.so (lock step `r8` = the default of rounds 1-2,
+    software team barriers `ppt`, decoupled teams `r8t`, 512-thread radix-16 `r16`) compute the same
+    columns as the product kernel: same arithmetic per bin, only the order of the float32 histogram sums differs, so dB
+    agrees to a few ulp and the palette index may differ by one step on a handful of cells.  One child process per
+    variant (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, diag, env in (("product", False, {}), (variant, True, {"EMSPEC_FUSED_VARIANT": variant})):
+        f = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _VARIANT_CHILD % dict(root=root, diag=diag), f],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(f)
+    a, b = outs["product"], outs[variant]
+    live = a["db"] > -100
+    assert np.max(np.abs(a["db"][live] - b["db"][live])) < 1e-3
+    diff = a["index"].astype(np.int16) - b["index"].astype(np.int16)
+    assert np.max(np.abs(diff)) <= 1
+    assert np.count_nonzero(diff) <= 1e-3 * diff.size
+    print(f"MEASURED variant {variant}: max |dB difference| {np.max(np.abs(a['db'][live] - b['db'][live])):.2e}, "
+          f"{np.count_nonzero(diff)} of {diff.size} palette indices differ by one step")
+
+
 @pytest.mark.parametrize("smoothing,agc", [(0.6, 0.0), (0.0, 1.0), (0.85, 0.7)])
 def test_display_postprocess(smoothing, agc):
     """Temporal smoothing + adaptive brightness over finished columns: batch (chunked IIR with
