@@ -168,6 +168,23 @@ struct TwLdsStrided {   // slot e of column lo at base[e*stride]  (base already 
     const float2* base; int stride;
     __device__ __forceinline__ float2 operator()(int e) const { return base[e * stride]; }
 };
+// The same fifteen slots from EIGHT reads: within a stage the upper half of the slots lies exactly a quarter turn
+// (N/4 table entries) beyond the lower half - slot mm + mloc/2 has exponent + (mloc/2 << B0) << (S0 + u) = + 2^(LOG2N-2) -
+// and the table is quarter-turn symmetric, tw[q + N/4] = (tw[q].y, -tw[q].x) exactly (enforced where the table is built,
+// DESIGN.md §3.1); negation is exact, so the butterflies are bit-identical.  (e is a compile-time constant after
+// unrolling; the two uses of a slot are one LDS read.)
+struct TwLdsSym16 {
+    const float2* base; int stride;
+    __device__ __forceinline__ float2 operator()(int e) const {
+        const int half = e < 8 ? 4 : (e < 12 ? 2 : (e < 14 ? 1 : 0));
+        const int first = e < 8 ? 0 : (e < 12 ? 8 : (e < 14 ? 12 : 14));
+        if (half && e - first >= half) {
+            const float2 w = base[(e - half) * stride];
+            return make_float2(w.y, -w.x);
+        }
+        return base[e * stride];
+    }
+};
 
 // row = largest r in [0,R) with ebin[r] <= kh ; -1 unless ebin[0] <= kh < ebin[R].
 // Exact float compares against the table: identical to the oracle's binary search.

@@ -107,7 +107,7 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
         float2 v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = sm[pb + poff(i)];
-        fft_stages_w<4, TwLdsStrided, PRIO>(v, TwLdsStrided{stw + lo, 1 << B0});   // PRIO builds (fused N = 16384) are also the register-lean ones
+        fft_stages_w<4, TwLdsSym16, PRIO>(v, TwLdsSym16{stw + lo, 1 << B0});   // PRIO builds (fused N = 16384) are also the register-lean ones
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm[pb + poff(i)] = v[i];
         wave_lds_sync();
