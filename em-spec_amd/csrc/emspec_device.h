@@ -130,8 +130,13 @@ __device__ __forceinline__ void fft_stages(float2 (&v)[1 << R], int lo, const fl
                 else if (q == 3 * (N / 8)) v[i + mloc] = cmul_tw(d, make_float2(-kC8, -kC8));
                 else v[i + mloc] = cmul_tw(d, tw[q]);
             } else {
-                const int q = (((i & (mloc - 1)) << B0) + lo) << s;
-                v[i + mloc] = cmul_tw(d, tw[q]);   // tw[0]=(1,-0), tw[N/4]=(0,-1): exact
+                // the upper half of a stage's butterflies lies a quarter turn beyond the lower half and the table is
+                // quarter-turn symmetric (tw[q + N/4] = (tw[q].y, -tw[q].x) exactly): one load serves both
+                const int mm = i & (mloc - 1);
+                const bool rot = mloc >= 2 && mm >= mloc / 2;
+                const int q = (((rot ? mm - mloc / 2 : mm) << B0) + lo) << s;
+                const float2 w = tw[q];   // tw[0]=(1,-0), tw[N/4]=(0,-1): exact
+                v[i + mloc] = cmul_tw(d, rot ? make_float2(w.y, -w.x) : w);
             }
         }
     }
