@@ -14,9 +14,9 @@ for dd in ("pmc_sq1", "pmc_sq2"):
             vals[r["Counter_Name"]] = float(r["Counter_Value"])
             wg = int(r["Workgroup_Size"])
 nw, wc = vals["SQ_WAVES"], vals["SQ_WAVE_CYCLES"]
-iters = 520   # 1024-column segments + 16 halo frames, two frames per iteration
+iters = (1047616.0 / (nw / (wg / 64)) + 16) / 2   # columns per workgroup + 16 halo frames, two frames per iteration (bench.py: 1,047,616 columns per launch)
 out = ["# SQ counters of the fused kernel for one bench.py batch launch (64 streams x 2^22 samples =",
-       f"# {nw / (wg / 64):.0f} workgroups x {wg // 64} waves, {iters} two-frame iterations each), two --pmc passes:",
+       f"# {nw / (wg / 64):.0f} workgroups x {wg // 64} waves, {iters:.0f} two-frame iterations each), two --pmc passes:",
        "# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES",
        "# rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS",
        "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles"]
