@@ -32,7 +32,7 @@ try:   # VALU issue rate against the chip's measured rate (tools/ubench/valu_rat
     kms = json.load(open(os.path.join(root, "profiles", f"{tag}_bench_n1.json")))["roofline"]["kernel_ms"]
     rate = vals["SQ_INSTS_VALU"] / (kms * 1e-3) / 1024
     out.append(f"VALU wave-instructions per second and SIMD: {rate:.3g} over the {kms:.2f} ms launch (the chip saturates at 7.4e8 v_fma_f32 / "
-               f"8.7e8 v_add_f32, profiles/{tag}_valu_rate.txt): {rate / 8.7e8:.0%}-{rate / 7.4e8:.0%} of the VALU issue rate")
+               f"8.7e8 v_add_f32, profiles/r02_valu_rate.txt): {rate / 8.7e8:.0%}-{rate / 7.4e8:.0%} of the VALU issue rate")
 except Exception as ex:
     out.append(f"(no bench line for the VALU-rate comparison: {ex})")
 open(os.path.join(root, "profiles", f"{tag}_sq_counters.txt"), "w").write("\n".join(out) + "\n")
