@@ -15,7 +15,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)   # latest run first (gpurun merges into the directory)
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bj = os.path.join(src, "bench_n1.json")
@@ -23,7 +23,7 @@ if os.path.exists(bj):
     shutil.copy(bj, os.path.join(dst, f"{tag}_bench_n1.json"))
 out = {}
 for d, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     vals = {}

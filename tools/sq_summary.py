@@ -6,7 +6,7 @@ src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 vals = {}
 for dd in ("pmc_sq1", "pmc_sq2"):
-    f = glob.glob(os.path.join(src, dd, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, dd, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # gpurun merges into the directory: take the latest run
     rows = [r for r in csv.DictReader(open(f)) if "fused4096" in r["Kernel_Name"]]
     big = max(int(r["Grid_Size"]) for r in rows)
     for r in rows:
