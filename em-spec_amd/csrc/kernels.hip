@@ -264,7 +264,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
         // frame's atomics are ordered by the fence + barrier, so column fin_col is complete: emit it and clear its
         // ring slot here.  Slot hist_slots is the always-empty column (used while the ring primes).
-        __threadfence();
+        // (A WORKGROUP-scope fence: the cells are read below by this same workgroup with agent-scope atomic loads, i.e.
+        // from the L2 the atomics were performed in; the agent-scope fence that stood here also wrote the L2 back -
+        // `buffer_wbl2 sc1` - which the end of the kernel does anyway: ~2 us of the call.)
+        __threadfence_block();
         __syncthreads();
         const int64_t slot = sk.fin_col >= 0 ? sk.fin_col % sk.hist_slots : sk.hist_slots;
         float* cells = sk.hist + (size_t)slot * pl.rows;
