@@ -333,8 +333,8 @@ __device__ __forceinline__ BinOut reassign_core(const PlanDev& pl, const Lookup&
 // when k-hat is out of range).
 __device__ __forceinline__ BinOut reassign_core_fast(const PlanDev& pl, const HintLookup& lk, int k,
                                                      const YT& m, const YT& c, const YT& p) {
-    const float Ar = (c.yr + c.yr) - (m.yr + p.yr), Ai = (c.yi + c.yi) - (m.yi + p.yi);
-    const float Br = (c.tr + c.tr) - (m.tr + p.tr), Bi = (c.ti + c.ti) - (m.ti + p.ti);
+    const float Ar = twice_minus(c.yr, m.yr + p.yr), Ai = twice_minus(c.yi, m.yi + p.yi);   // (c + c) - s, rounded once either way
+    const float Br = twice_minus(c.tr, m.tr + p.tr), Bi = twice_minus(c.ti, m.ti + p.ti);
     const float Dr = m.yr - p.yr, Di = m.yi - p.yi;
     const float den = __builtin_fmaf(Ar, Ar, Ai * Ai);
     BinOut o;
