@@ -152,6 +152,8 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
                         : (double)e->custom_edges_hz[r] * (double)n / (double)e->cfg.sample_rate;
         for (int r = 0; r < R; ++r)
             if (!(eb[r] < eb[r + 1])) return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges are not strictly increasing");
+        p.h_e0 = eb[0];
+        p.h_eR = eb[R];
         HIPCHK(e, hipMalloc(&p.d_tw64, sizeof(double) * n));
         HIPCHK(e, hipMalloc(&p.d_ebin64, sizeof(double) * (R + 1)));
         HIPCHK(e, hipMemcpy(p.d_tw64, tw.data(), sizeof(double) * n, hipMemcpyHostToDevice));
@@ -195,6 +197,10 @@ ExactPlanDev exact_plan_dev(const emspec_engine* e, const Plan& p, int hop, int 
     while ((1 << log2n) < p.n) ++log2n;
     d.qscale = std::ldexp(1.0, 52 - (2 * log2n - 4));
     d.pmax = std::ldexp(1.0, 61) / d.qscale;
+    d.e0 = p.h_e0;
+    d.eR = p.h_eR;
+    d.l2e0 = std::log2((float)p.h_e0);
+    d.rscale = (float)d.rows / (std::log2((float)p.h_eR) - d.l2e0);
     return d;
 }
 ExactDbMap exact_db_map(const emspec_engine* e, int n, const ExactPlanDev& pd) {
@@ -445,6 +451,10 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     int rc;
     const ExactPlanDev pd = exact_plan_dev(e, p, hop, reassign);
     const ExactDbMap m = exact_db_map(e, n, pd);
+    if (exact_fused_supported(n, pd)) {   // one kernel, no records (exact_fused.hip.inc)
+        HIPCHK(e, launch_exact_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
+        return EMSPEC_OK;
+    }
     const size_t Kp = (size_t)exact_record_stride(n);
     const size_t q_per_stream = (size_t)C * Kp * sizeof(long long), key_per_stream = (size_t)C * Kp * sizeof(uint32_t);
     const size_t budget = (size_t)12 << 30;
@@ -558,6 +568,23 @@ int emspec_debug_recip(emspec_engine* e, const float* d, int64_t count, float* o
     return EMSPEC_OK;
 }
 
+int emspec_debug_recip64(emspec_engine* e, const double* d, int64_t count, double* out_short, double* out_ieee) {
+    if (!e || !d || !out_short || !out_ieee || count < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    double *d_in = nullptr, *d_a = nullptr, *d_b = nullptr;
+    hipError_t r = hipMalloc(&d_in, count * 8 + 8);
+    if (r == hipSuccess) r = hipMalloc(&d_a, count * 8 + 8);
+    if (r == hipSuccess) r = hipMalloc(&d_b, count * 8 + 8);
+    if (r == hipSuccess) r = hipMemcpyAsync(d_in, d, count * 8, hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = launch_recip64_probe(d_in, count, d_a, d_b, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_short, d_a, count * 8, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipMemcpyAsync(out_ieee, d_b, count * 8, hipMemcpyDeviceToHost, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_in); (void)hipFree(d_a); (void)hipFree(d_b);
+    HIPCHK(e, r);
+    return EMSPEC_OK;
+}
+
 // Diagnostic (not part of the product path): run the stamped build of the fused kernel and
 // return, per workgroup and wave, the cycles spent in each barrier-delimited phase.
 // cycles: [groups][waves][8 slots] uint64 on the HOST; *groups receives the workgroup count and
@@ -566,11 +593,29 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
                               int32_t reassign, float* db_dev, uint8_t* index_dev, uint64_t* cycles, int64_t* groups,
                               int32_t* waves) {
     if (!e || !pcm_dev || !groups) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
-    if (!fused_supported(n, hop, e->cfg.rows, reassign)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused kernel for this shape");
     HIPCHK(e, hipSetDevice(e->device));
     Plan* p;
     int rc;
     if ((rc = get_plan(e, n, &p))) return rc;
+    if (e->exact()) {   // the stamped build of exact_fused4096_kernel (waves: 16; slots: exact_fused.hip.inc)
+        const ExactPlanDev xpd = exact_plan_dev(e, *p, hop, reassign);
+        if (!exact_fused_supported(n, xpd)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused exact kernel for this shape");
+        const ExactDbMap xm = exact_db_map(e, n, xpd);
+        const int64_t Cx = emspec_num_columns(L, n, hop);
+        HIPCHK(e, launch_exact_fused(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
+        if (waves) *waves = 16;
+        if (!cycles) return EMSPEC_OK;
+        unsigned long long* dx = nullptr;
+        const size_t xbytes = (size_t)(*groups) * 16 * 8 * sizeof(unsigned long long);
+        HIPCHK(e, hipMalloc(&dx, xbytes));
+        hipError_t xr = launch_exact_fused(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, db_dev, nullptr, index_dev, e->stream, dx, groups);
+        if (xr == hipSuccess) xr = hipMemcpyAsync(cycles, dx, xbytes, hipMemcpyDeviceToHost, e->stream);
+        if (xr == hipSuccess) xr = hipStreamSynchronize(e->stream);
+        (void)hipFree(dx);
+        HIPCHK(e, xr);
+        return EMSPEC_OK;
+    }
+    if (!fused_supported(n, hop, e->cfg.rows, reassign)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused kernel for this shape");
     const PlanDev pd = plan_dev(e, *p, hop, reassign);
     const DbMap m = db_map(e, n);
     const int64_t C = emspec_num_columns(L, n, hop);

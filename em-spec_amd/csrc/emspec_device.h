@@ -72,6 +72,9 @@ struct ExactPlanDev {
     double pfloor;       // gate on |X_h|^2
     double pmax;         // upper gate = 2^61 / qscale
     double qscale;       // fixed-point units per unit of |X_h|^2: 2^52 / (N/4)^2, a power of two
+    // for the branch-free per-bin core of exact_fused.hip.inc (log-spaced rows): the table's ends and the float32 log2 hint
+    double e0, eR;       // ebin[0], ebin[rows]
+    float l2e0, rscale;  // log2(e0), rows / (log2(eR) - log2(e0))
 };
 struct ExactDbMap { double scale, lo, inv_range, gate, inv_q; };
 

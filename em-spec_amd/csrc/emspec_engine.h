@@ -20,6 +20,7 @@ struct Plan {
     // EXACT mode (cfg.mode == EMSPEC_MODE_EXACT): the binary64 tables
     double2* d_tw64 = nullptr;
     double* d_ebin64 = nullptr;
+    double h_e0 = 0.0, h_eR = 0.0;   // ends of the binary64 edge table
 };
 }  // namespace emspec
 

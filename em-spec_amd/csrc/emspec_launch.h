@@ -55,6 +55,12 @@ int exact_record_stride(int n);
 hipError_t launch_exact_tile_scatter(const long long* rec_q, const uint32_t* rec_key, int n, const ExactPlanDev& pl,
                                      const ExactDbMap& m, const uint8_t* lut, int S, int64_t C, float* db, uint8_t* rgba,
                                      uint8_t* index, hipStream_t st);
+// EXACT mode, one kernel (exact_fused.hip.inc): N = 4096 at every hop whose u64 column ring fits in LDS
+bool exact_fused_supported(int n, const ExactPlanDev& pl);
+hipError_t launch_exact_fused(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
+                              int64_t L, int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
+                              unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
+int exact_fused_read_errflag();   // non-zero: a bounded spin of the fused exact kernel timed out on this device (results invalid)
 hipError_t launch_exact_finalize(const unsigned long long* cells, int64_t ncells, const ExactDbMap& m, const uint8_t* lut,
                                  float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
 
@@ -94,6 +100,7 @@ hipError_t launch_row_lookup_probe(const float* ebin, int rows, const float* kh,
                                    int32_t* out_exact, hipStream_t st);
 hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st);
 hipError_t launch_recip_probe(const float* d, int64_t count, float* out_short, float* out_ieee, hipStream_t st);
+hipError_t launch_recip64_probe(const double* d, int64_t count, double* out_short, double* out_ieee, hipStream_t st);
 #endif
 
 }  // namespace emspec

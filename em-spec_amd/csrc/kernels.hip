@@ -641,3 +641,4 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
 #include "post.hip.inc"
 #include "pack.hip.inc"
 #include "exact.hip.inc"
+#include "exact_fused.hip.inc"

@@ -21,9 +21,14 @@ int emspec_debug_row_lookup(emspec_engine* e, int32_t n, const float* kh, int64_
  * `count` host values: out_short[i], out_ieee[i].  They must agree bit for bit for 2^-96 < d < 2^126. */
 int emspec_debug_recip(emspec_engine* e, const float* d, int64_t count, float* out_short, float* out_ieee);
 
+/* The same for the EXACT mode's binary64 reciprocal (recip_normal64, exact_fused.hip.inc) and 1.0 / d: bit for bit equal for
+ * 2^-700 < d < 2^1000. */
+int emspec_debug_recip64(emspec_engine* e, const double* d, int64_t count, double* out_short, double* out_ieee);
+
 /* Run the stamped build of the fused kernel on device-resident pcm and return, per
  * workgroup and wave, the shader-clock cycles spent in each barrier-delimited phase:
- * cycles[groups][waves][8] (host).  Call with cycles == NULL to get *groups / *waves. */
+ * cycles[groups][waves][8] (host).  Call with cycles == NULL to get *groups / *waves.
+ * On an EXACT-mode engine: the stamped build of exact_fused4096_kernel (slots: tools/phase_cycles_exact.py). */
 int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S, int64_t L,
                               int32_t n, int32_t hop, int32_t reassign, float* db_dev,
                               uint8_t* index_dev, uint64_t* cycles, int64_t* groups,

@@ -39,7 +39,7 @@ def test_header_symbols_exported():
 
 def test_diag_library_adds_only_the_debug_header():
     dbg = declared_functions("emspec_debug.h")
-    assert "emspec_debug_row_lookup" in dbg and "emspec_debug_phase_cycles" in dbg and "emspec_debug_recip" in dbg
+    assert "emspec_debug_row_lookup" in dbg and "emspec_debug_phase_cycles" in dbg and "emspec_debug_recip" in dbg and "emspec_debug_recip64" in dbg
     assert exported_functions(emspec.DIAG_LIB_PATH) == sorted(set(declared_functions("emspec.h")) | set(dbg))
     out = subprocess.run(["strings", "-n", "6", emspec.LIB_PATH], capture_output=True, text=True).stdout
     for needle in ("EMSPEC_FUSED_VARIANT", "EMSPEC_NO_FUSED", "EMSPEC_SEGLEN", "EMSPEC_NO_WALK", "fused4096_r8t", "fused4096_r8_kernel", "occupy_kernel"):

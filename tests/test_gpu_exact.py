@@ -262,3 +262,120 @@ def test_exact_nan_and_inf_samples(xengine):
     assert np.array_equal(pw[0], opw, equal_nan=True)
     poisoned = [j for j in range(frames) if j * hop <= 5000 < j * hop + n]
     assert poisoned and np.all(row[0][poisoned] == -1) and np.all(q[0][poisoned] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the one-kernel path of the mode at N = 4096 (exact_fused.hip.inc: u64 ring resident in LDS, the binary64 planes
+# laid over its first 64 KB, branch-free per-bin core with a 7-instruction reciprocal).  Everything above already runs on
+# it at N = 4096; the cases below aim at what is new in it.
+
+def test_short_reciprocal64_equals_ieee_division(diag_engine):
+    """recip_normal64 (v_rcp_f64 + the two Newton steps + the residual correction of hipcc's own division expansion,
+    without its scaling / special-case instructions) == 1.0 / d bit for bit on the range the per-bin gate guarantees."""
+    import ctypes as C
+    lib = emspec.load(diag=True)
+    lib.emspec_debug_recip64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(20264)
+    mant = np.concatenate([rng.integers(0, 1 << 52, 3_000_000, dtype=np.uint64),
+                           np.array([0, 1, 2, 3, (1 << 52) - 1, (1 << 52) - 2, 1 << 51, (1 << 51) - 1, (1 << 51) + 1,
+                                     0x6A09E667F3BCD, 0x6A09E667F3BCC, 0x6A09E667F3BCE], np.uint64)])    # sqrt(2) - 1 and neighbours
+    expo = rng.integers(1023 - 699, 1023 + 999, mant.size, dtype=np.uint64)
+    expo[-12:] = 1023
+    vals = ((expo << np.uint64(52)) | mant).view(np.float64)
+    # every binade edge of the range and the gate's own ends at the default configuration
+    extra = np.concatenate([np.ldexp(1.0, np.arange(-699, 1000)), np.nextafter(np.ldexp(1.0, np.arange(-699, 1000)), 0),
+                            np.nextafter(np.ldexp(1.0, np.arange(-699, 999)), np.inf), [64e-8, 2.0 ** 35]])
+    vals = np.ascontiguousarray(np.concatenate([vals, extra]))
+    a = np.empty_like(vals)
+    b = np.empty_like(vals)
+    assert lib.emspec_debug_recip64(diag_engine._h, vals.ctypes.data, vals.size, a.ctypes.data, b.ctypes.data) == 0
+    bad = a.view(np.uint64) != b.view(np.uint64)
+    assert not bad.any(), f"{bad.sum()} of {vals.size} reciprocals differ, first d = {vals[bad][0]!r}"
+    # ... and the GPU's division is the IEEE one (what the CPU bit model computes)
+    assert np.array_equal(b.view(np.uint64), (1.0 / vals).view(np.uint64))
+
+
+FUSED_CASES = [  # hop, frames, S, reassign, rows, seglen (0: the launcher's plan), engine settings
+    (256, 300, 2, True, 1024, 64, {}),          # several segments per stream: halo frames, ring restarts
+    (256, 129, 1, True, 1024, 65, {}),          # odd segment length, a last segment of one column
+    (256, 5, 2, True, 1024, 0, {}),             # fewer frames than the reassignment reach
+    (256, 1, 1, True, 1024, 0, {}),             # one frame
+    (512, 150, 2, True, 1024, 0, {}),           # D = 4: 10 ring slots (80 KB), the planes cover most of the ring
+    (1024, 90, 2, True, 1024, 70, {}),          # D = 2: the ring (48 KB) is smaller than the planes
+    (300, 70, 1, True, 1024, 0, {}),            # a hop that is no power of two (D = 7)
+    (256, 120, 2, False, 1024, 64, {}),         # reassignment off: D = 0, three slots, the branchy per-bin core
+    (256, 90, 2, True, 512, 0, {}),             # fewer rows
+    (256, 90, 1, True, 64, 0, {}),
+    (256, 90, 2, True, 1024, 0, {"power_floor": 0.0}),   # no power floor: the generic core (recip_normal64's range is not guaranteed)
+    (256, 60, 1, True, 1024, 0, {"gain": 3.5, "db_range": 58.0, "gate_db": -65.0}),
+]
+
+
+@pytest.mark.parametrize("hop,frames,S,reassign,rows,seglen,kw", FUSED_CASES)
+def test_exact_fused_kernel_shapes(hop, frames, S, reassign, rows, seglen, kw, monkeypatch):
+    """exact_fused4096_kernel over its shape space: bytes equal to the binary64 bit model (dB bits, palette index, RGBA)."""
+    n = 4096
+    if seglen:
+        monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
+    pcm = _pcm(n, hop, frames, S=S, extra=5)
+    with emspec.Engine(mode=emspec.MODE_EXACT, diag=True, rows=rows, **kw) as e:
+        out = e.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
+    odb, orgba, oidx, _ = O.batch_exact(O.make_cfg(n, hop, reassign, rows=rows, **kw), pcm)
+    assert out["db"].shape == odb.shape == (S, frames, rows)
+    assert np.array_equal(out["index"], oidx), f"{np.sum(out['index'] != oidx)} palette indices differ"
+    assert np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32)), \
+        f"{np.sum(out['db'].view(np.uint32) != odb.view(np.uint32))} dB cells differ"
+    assert np.array_equal(out["rgba"], orgba)
+
+
+def test_exact_fused_custom_axis_uses_generic_core(monkeypatch):
+    """A warped (not log-spaced) axis: the fused kernel runs its generic per-bin core (binary search of the edge table)."""
+    n, hop, frames = 4096, 256, 80
+    monkeypatch.setenv("EMSPEC_SEGLEN", "64")
+    pcm = _pcm(n, hop, frames, S=1)
+    edges = emspec.warped_edges_hz(1024, 20.0, 24000.0, 2.0, 1.6)
+    with emspec.Engine(mode=emspec.MODE_EXACT, diag=True) as e:
+        e.set_row_edges_hz(edges)
+        O.set_custom_edges_hz(edges)
+        try:
+            out = e.batch(pcm, n, hop, True, want=("db", "index"))
+            odb, _, oidx, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+        finally:
+            O.set_custom_edges_hz(None)
+    assert np.array_equal(out["index"], oidx) and np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
+
+
+def test_exact_full_size_spot_checks_against_bit_model(xengine):
+    """BASELINE configs[2] at full size in EXACT mode (64 streams x 2^22 samples, 1,047,616 columns, one launch of the fused
+    kernel: 256 workgroups of 4,093 columns): random (stream, column) cells, the first and last columns of a stream and the
+    columns on both sides of every kind of segment boundary against the bit model evaluated on the slice of audio that can
+    reach them (column c depends on frames c-8 .. c+8 only) - array_equal on the dB bits and the palette index; a second
+    run gives the same bytes."""
+    import torch
+    n, hop, D = 4096, 256, 8
+    S, L = 64, 1 << 22
+    base = synth.streams(4, L)
+    rng = np.random.default_rng(4242)
+    pcm = np.stack([np.roll(base[s % 4], 1237 * s) * (0.5 + 0.5 * ((s * 7) % 5) / 4) for s in range(S)]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pcm).to(dev)
+    Cn = (L - n) // hop + 1
+    db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, Cn, 1024), dtype=torch.uint8, device=dev)
+    xengine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    cfg = O.make_cfg(n, hop, True)
+    seg = -(-Cn // 4)      # 64 streams on 256 CUs: four segments per stream
+    cols = [0, 1, 7, 8, 9, Cn - 1, Cn - 2, Cn - 9] + [k * seg + d for k in (1, 2, 3) for d in (-9, -1, 0, 1, 8)] + \
+        list(rng.integers(20, Cn - 20, 10))
+    for c in cols:
+        s = int(rng.integers(0, S))
+        f0, f1 = max(0, c - D), min(Cn - 1, c + D)
+        odb, _, oidx, _ = O.batch_exact(cfg, pcm[s, f0 * hop:f1 * hop + n][None], want=("db", "index"), threads=1)
+        assert np.array_equal(db[s, c].cpu().numpy().view(np.uint32), odb[0, c - f0].view(np.uint32)), f"dB bits differ at stream {s} column {c}"
+        assert np.array_equal(idx[s, c].cpu().numpy(), oidx[0, c - f0]), f"index differs at stream {s} column {c}"
+    chk = (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))
+    db.zero_(); idx.zero_()
+    xengine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    assert chk == (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))

@@ -2,7 +2,8 @@
 """A/B two builds of libemspec.so on the same box: alternates them (child process each), times the column kernel of a
 bench workload with HIP events, prints ms per launch.  Box-to-box spread is ~2 %, so variants are compared here.
    python tools/ab_kernel.py libA.so libB.so [--workload batch64|n16384] [--rounds 3]
-A library given as path@VARIANT runs with EMSPEC_FUSED_VARIANT=VARIANT (libemspec_diag.so only).
+A library given as path@VARIANT runs with EMSPEC_FUSED_VARIANT=VARIANT, path@NAME=value with that environment variable
+(libemspec_diag.so only).
 """
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ from bench import synth_device, time_launches
 n, hop = %(n)d, %(hop)d
 dev = torch.device("cuda", 0)
 eng = emspec.Engine(mode=emspec.MODE_EXACT if %(exact)d else emspec.MODE_FAST)
-S, L = (16 if %(exact)d else 64), 1 << 22
+S, L = (%(streams)d or (16 if %(exact)d else 64)), 1 << 22
 C = emspec.num_columns(L, n, hop)
 pcm = synth_device(S, L, 0, dev)
 db = torch.empty((S, C, eng.rows), dtype=torch.float32, device=dev)
@@ -52,6 +53,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--n", type=int, default=0, help="FFT size (overrides --workload)")
 ap.add_argument("--hop", type=int, default=0)
 ap.add_argument("--exact", action="store_true", help="EXACT mode engine, 16 streams")
+ap.add_argument("--streams", type=int, default=0, help="streams (default 64; 16 with --exact)")
 ap.add_argument("--dump", action="store_true", help="time the per-bin parity dump (16 streams x 2^20 samples) instead of the batch")
 a = ap.parse_args()
 n, hop, reps = (16384, 512, 4) if a.workload == "n16384" else (4096, 256, 8)
@@ -61,8 +63,13 @@ res = {l: [] for l in a.libs}
 for r in range(a.rounds):
     for lib in a.libs:
         path, _, variant = lib.partition("@")
-        env = dict(os.environ, EMSPEC_FUSED_VARIANT=variant) if variant else None
-        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(path), n=n, hop=hop, reps=reps, dump=int(a.dump), exact=int(a.exact))],
+        env = None
+        if variant:
+            env = dict(os.environ)
+            for item in variant.split(","):      # path@NAME=value[,NAME2=value2]
+                name, eq, val = item.partition("=")
+                env.update({name: val} if eq else {"EMSPEC_FUSED_VARIANT": item})
+        out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, lib=os.path.abspath(path), n=n, hop=hop, reps=reps, dump=int(a.dump), exact=int(a.exact), streams=a.streams)],
                              capture_output=True, text=True, timeout=300, env=env)
         if out.returncode != 0:
             sys.exit(out.stderr[-2000:])
