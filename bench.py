@@ -46,25 +46,40 @@ def executed_flops_per_column(n, rows=1024):
 
 
 def sources_sha():
-    """sha1 over the kernel / C-ABI sources: profile-derived numbers are only quoted when they were taken on these."""
-    h = hashlib.sha1()
-    base = os.path.join(ROOT, "em-spec_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(base, "**", "*"), recursive=True)):
-        if os.path.isfile(f) and f.endswith((".hip", ".inc", ".h", ".cpp")):
-            h.update(os.path.relpath(f, base).encode())
-            h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    """sha1 over the kernel / C-ABI sources (tools/sources_sha.py: the definition the library's Makefile compiles in):
+    profile-derived numbers are only quoted when they were taken on these."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import sources_sha as _ss
+    finally:
+        sys.path.pop(0)
+    return _ss.sources_sha(ROOT)
 
 
-def profile_for(workload):
+def library_sha():
+    """The digits the LOADED libemspec.so was built from (emspec_build_info); None when it cannot say."""
+    try:
+        import emspec
+        info = emspec.build_info()
+        for tok in info.split():
+            if tok.startswith("sources="):
+                return tok[len("sources="):]
+    except Exception:
+        pass
+    return None
+
+
+def profile_for(workload, lib_sha="tree"):
     """Committed rocprofv3 summary of this workload (profiles/*_<workload>.json, written by tools/profile_json.py),
-    newest first; returns (dict, fresh) where fresh says the kernels are unchanged since it was taken."""
+    newest first; returns (dict, fresh) where fresh says that the source tree AND the loaded library (lib_sha: what
+    emspec_build_info reports; "tree" = do not check, for callers without a library) are the ones it was taken on - a
+    stale prebuilt .so must not be quoted with a fresh tree's counters."""
     sha = sources_sha()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}.json")))[::-1]:
         try:
             d = json.load(open(f))
             d["file"] = os.path.relpath(f, ROOT)
-            return d, d.get("sources_sha") == sha
+            return d, d.get("sources_sha") == sha and (lib_sha == "tree" or lib_sha == sha)
         except Exception:
             continue
     return None, False
@@ -200,6 +215,38 @@ def js_baseline(n, hop, seconds=5.0):
         return None
 
 
+class Watchdog:
+    """A per-step deadline on a daemon thread: a rank that stops making progress (a peer died inside a collective, a kernel
+    never returns) ends its process with exit code 1 - the launcher then stops the job - instead of hanging until the
+    driver's own limit.  No re-exec of a process that touched the GPU: the thread only calls os._exit."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.deadline, self.what = rank, None, ""
+        self.lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, seconds, what):
+        with self.lock:
+            self.deadline, self.what = time.monotonic() + seconds, what
+
+    def disarm(self):
+        with self.lock:
+            self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                late = self.deadline is not None and time.monotonic() > self.deadline
+                what = self.what
+            if late:
+                sys.stderr.write(f"[bench rank {self.rank}] watchdog: {what} exceeded its deadline - ending this rank (exit 1)\n")
+                sys.stderr.flush()
+                os._exit(1)
+
+
 def time_launches(fn, stream, reps):
     """average HIP-event duration (ms) of reps back-to-back calls of fn on `stream` (after one untimed call)"""
     fn()
@@ -251,14 +298,22 @@ def main():
                          "and reductions through it, two RCCL communicators in the process)")
     ap.add_argument("--root-streams", type=int, default=-1,
                     help="N>1: streams on rank 0, which also expands the gathered columns (default: try a few splits, keep the fastest)")
-    ap.add_argument("--gather-packed", action="store_true",
-                    help="N>1 / loopback: the root keeps the gathered images packed (EMSPEC_GATHER_PACKED) instead of expanding them")
+    ap.add_argument("--gather-expand", action="store_true",
+                    help="N>1 / loopback: time the gather whose root EXPANDS every rank's image into plain [streams][columns][rows] arrays; "
+                         "the default keeps the lossless packed images on the root (EMSPEC_GATHER_PACKED: directory + images, expanded on "
+                         "demand with emspec_wire_unpack) and reports the expanding form beside it")
+    ap.add_argument("--step-deadline-factor", type=float, default=20.0,
+                    help="watchdog: a timed step may take this many times the slowest warm-up step (at least --step-deadline-min) before the rank exits 1")
+    ap.add_argument("--step-deadline-min", type=float, default=30.0, help="watchdog: the shortest per-step deadline, seconds")
+    ap.add_argument("--hang-rank", type=int, default=-1, help="TEST HOOK: this rank stops (sleeps) at --hang-at-step of the timed run")
+    ap.add_argument("--hang-at-step", type=int, default=1)
     ap.add_argument("--trial-budget-s", type=float, default=60.0,
                     help="N>1: wall-clock budget of the stream-split trials; when it is spent the remaining splits are skipped "
                          "(none measured: the modelled split, root 8 streams lighter per other rank, is used)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (torch gather via host tensors)")
     args = ap.parse_args()
+    args.gather_packed = not args.gather_expand
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -299,6 +354,7 @@ def main():
     S = args.streams or (1 if args.workload == "single" else 64)     # streams per GPU (the job has world x S)
     L = 1 << args.log2_samples
     eng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT if args.mode == "exact" else emspec.MODE_FAST)
+    lib_sha = library_sha()       # what the LOADED library was built from; counters are quoted only when it is the tree's and the profile's
     R = eng.rows
     C = emspec.num_columns(L, n, hop)
     if args.workload == "paritydump":
@@ -323,13 +379,13 @@ def main():
         ms = time_launches(dump, cur, args.steps)
         bpc = 4 * hop + 12 * K
         rf = roofline(Sd * Cd, bpc, ms, "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples")
-        pp, pf = profile_for("paritydump")
+        pp, pf = profile_for("paritydump", lib_sha)
         rf["traffic"] = pp.get("hbm_bytes_per_launch") if (pp and pf) else None
         line = {"metric": "parity-dump columns/sec (4096-pt, hop 256, per-bin power + column + row)", "value": Sd * Cd / (ms * 1e-3),
                 "unit": "columns/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "per-bin parity dump, 16 streams x 2^20 samples, FFT 4096, hop 256, reassignment ON",
-                           "columns_per_step": Sd * Cd, "sources_sha": sources_sha()},
+                           "columns_per_step": Sd * Cd, "sources_sha": sources_sha(), "library": emspec.build_info()},
                 "roofline": rf, "cpu_baseline": None}
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
@@ -460,15 +516,26 @@ def main():
             while self.pending:
                 self.do_gather(*self.pending.pop(0))
 
-        def run(self, steps, timed=False):
-            """barrier, `steps` steps (and the gathers they owe), barrier; returns the elapsed seconds, max over ranks."""
+        def run(self, steps, timed=False, deadline_s=None):
+            """barrier, `steps` steps (and the gathers they owe), barrier; returns the elapsed seconds, max over ranks.
+            deadline_s: the watchdog ends this rank when one step (or the closing barrier) takes longer."""
             self.wire_bytes[:] = [0, 0]
+            if deadline_s:
+                dog.arm(deadline_s, "the opening barrier")
             barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
+            for i in range(steps):
+                if deadline_s:
+                    dog.arm(deadline_s, f"step {i}")
+                if timed and rank == args.hang_rank and i == args.hang_at_step:     # test hook: a rank that stops making progress
+                    dog.disarm()
+                    time.sleep(3600)
                 self.step(timed)
+            if deadline_s:
+                dog.arm(deadline_s, "the last gather + closing barrier")
             self.flush()
             barrier()
+            dog.disarm()
             el = time.perf_counter() - t0
             if dist_on:
                 tmax = torch.tensor([el], dtype=torch.float64, device=gdev)
@@ -476,6 +543,7 @@ def main():
                 el = float(tmax.item())
             return el
 
+    dog = Watchdog(rank)
     if dist_on and gather_mode == "torch":
         # open the point-to-point connections the gather uses before anything is timed
         probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
@@ -520,10 +588,19 @@ def main():
             counts = shard.root_light_counts(world, total_streams, 0, max(args.chunks, total_streams - (world - 1) * (S + S // 8)))
 
     job = Job(counts)
+    warm_s = 0.0
+    dog.arm(600.0, "the warm-up")       # (the first gather opens RCCL's connections; a peer that never joins must not hang the job)
     for _ in range(max(args.warmup, 1 if gathering else 0)):   # the first gather opens RCCL's connections: never timed
+        t0w = time.perf_counter()
         job.step()
+        job.flush()
+        torch.cuda.synchronize(dev)
+        warm_s = max(warm_s, time.perf_counter() - t0w)
     job.flush()
-    elapsed = job.run(args.steps, timed=True)
+    dog.disarm()
+    step_deadline = max(args.step_deadline_min, args.step_deadline_factor * warm_s)
+    elapsed = job.run(args.steps, timed=True, deadline_s=step_deadline)
+    eng.device_status()           # raises if a kernel flagged a protocol error during the timed run (its columns would be invalid)
     wire_bytes = job.wire_bytes
     if dist_on:
         wb = torch.tensor(wire_bytes, dtype=torch.float64, device=gdev)
@@ -531,11 +608,25 @@ def main():
         wire_bytes = [float(wb[0].item()), float(wb[1].item())]
     # the same job with the images kept packed on the root (EMSPEC_GATHER_PACKED: nothing is lost, the root only receives and
     # expands on demand): three more steps after the timed run, reported beside the headline, never as the headline
-    packed_cps = None
+    packed_cps = expand_cps = None
     if gathering and gather_mode == "lib" and not args.gather_packed:     # (also in the one-GPU loopback rehearsals)
         job.switch_to_packed()
-        job.run(1)
-        packed_cps = total_streams * C * 3 / job.run(3)
+        job.run(1, deadline_s=step_deadline)
+        packed_cps = total_streams * C * 3 / job.run(3, deadline_s=step_deadline)
+    elif gathering and gather_mode == "lib":
+        # the default line times the packed form; the expanding form (the root turns every image back into plain arrays, as at
+        # N = 1) runs three steps after it on the same split and is reported beside it
+        args_packed_was = job.packed
+        job.flush()
+        torch.cuda.synchronize(dev)
+        job.packed = False
+        if rank == 0:
+            job.gathered = None
+            job.gathered = [torch.empty((sum(pr[ci][1] - pr[ci][0] for pr in job.per_rank), C, R), dtype=torch.uint8, device=dev)
+                            for ci in range(job.nch)]
+        job.run(1, deadline_s=step_deadline)
+        expand_cps = total_streams * C * 3 / job.run(3, deadline_s=step_deadline)
+        job.packed = args_packed_was
     S_nominal = S
     # every rank's own column-kernel time per step (HIP events on its launch stream), gathered for the line
     my_kms = float(np.mean([a.elapsed_time(b) for a, b in job.kev])) if job.kev else 0.0
@@ -548,7 +639,7 @@ def main():
     # what the root's expand costs by itself: one other rank's chunk worth of columns, packed and expanded standalone,
     # times the (world - 1) images per gather and the chunks per step
     expand_ms = None
-    if rank == 0 and gathering and gather_mode == "lib" and not args.gather_packed:
+    if rank == 0 and gathering and gather_mode == "lib":
         a, b = job.bounds[0]
         src = job.idx_bufs[0][a:b]
         wire = torch.empty((emspec.wire_bound((b - a) * C, R),), dtype=torch.uint8, device=dev)
@@ -573,7 +664,7 @@ def main():
         rf["algorithmic_bytes_per_launch"] = S * C * bytes_per_col
         prof, fresh = (None, False)
         if S == 64 and args.log2_samples == 22:
-            prof, fresh = profile_for(args.workload)
+            prof, fresh = profile_for(args.workload if args.mode == "fast" else args.workload.replace("batch64", "exact64"), lib_sha)
         rf["traffic"] = prof["hbm_bytes_per_launch"] if (prof and fresh and "hbm_bytes_per_launch" in prof) else None
         rf["traffic_source"] = (f"{prof['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; sources {prof['sources_sha']}"
                                 f"{'' if fresh else ', STALE: kernels changed since, traffic withheld'})") if prof else None
@@ -581,7 +672,9 @@ def main():
               f"{'ON' if args.reassign else 'OFF'}, {R} log-frequency rows, outputs float32 dB + uint8 palette index")
         if gathering:
             wl += (f"; gather of the palette-index columns to rank 0 in {nch} overlapped chunks per step by "
-                   + ("libemspec over RCCL (emspec_gather_columns, packed wire image)" if gather_mode == "lib"
+                   + (("libemspec over RCCL (emspec_gather_columns, lossless packed wire image; the root "
+                       + ("KEEPS the images packed: directory + images, expanded on demand by emspec_wire_unpack)" if args.gather_packed
+                          else "expands every image into plain [streams][columns][rows] arrays)")) if gather_mode == "lib"
                       else "torch.distributed.gather (raw columns)"))
         line = {
             "metric": "reassigned spectrogram columns/sec (4096-pt, hop 256, 48 kHz)" if n == 4096 else
@@ -591,7 +684,8 @@ def main():
             "vs_baseline": None, "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
             "config": {"workload": wl + ("; EXACT mode (binary64, 64-bit fixed-point histogram)" if args.mode == "exact" else ""), "streams_per_gpu": S_nominal, "streams_per_rank": counts, "samples_per_stream": L, "columns_per_step": cols_per_step,
                        "parallelism": f"streams sharded {world} way(s)", "fused_kernel": eng.fused(n, hop, True),
-                       "sources_sha": sources_sha()},
+                       "sources_sha": sources_sha(), "library": emspec.build_info(),
+                       "library_matches_sources": lib_sha == sources_sha()},
             "roofline": rf,
         }
         if gathering:
@@ -601,6 +695,8 @@ def main():
                               "rccl_world": eng.comm_world if gather_mode == "lib" else None,      # what RCCL itself reports
                               "root_keeps_images_packed": bool(args.gather_packed and gather_mode == "lib"),
                               "packed_columns_per_s": packed_cps,     # the same split with EMSPEC_GATHER_PACKED (3 steps after the timed run)
+                              "expanding_columns_per_s": expand_cps,  # ... or, when the packed form was timed, with the root expanding
+                              "step_deadline_s": step_deadline,
                               "kernel_ms_per_rank": rank_kms,                 # column-kernel time per step on every rank (HIP events)
                               "streams_per_rank": counts,
                               "root_expand_ms_standalone": expand_ms}
@@ -629,6 +725,27 @@ def main():
             rc["valu_util"] = None
             rc["source"] = f"{prof['file']} is stale (kernels changed since): counter-derived fields withheld"
         line["roofline_compute"] = rc
+        # the bound the kernel really sits under, in the same shape as `roofline`: VALU issue in the cycle domain (a wave64
+        # vector instruction holds its SIMD's pipe 2 cycles - 4 for binary64 - MI355X_MICROARCH.md), with the LDS pipe beside it
+        if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
+            cyc = 4.0 if args.mode == "exact" else 2.0
+            rate = prof["valu_insts_per_column"] * (S * C) / (k_avg_ms * 1e-3)
+            peak = SIMDS * prof["clock_ghz"] * 1e9
+            sq = prof.get("sq") or {}
+            lds_busy = (sq.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * prof["rocprof_median_ms"] * 1e-3 * prof["clock_ghz"] * 1e9)
+                        if prof.get("rocprof_median_ms") else None)
+            line["roofline_valu"] = {
+                "bound": "valu-issue", "achieved": rate * cyc / 1e9, "peak": peak / 1e9, "unit": "G SIMD-cycles/s",
+                "frac": rate * cyc / peak, "cycles_per_wave_instruction": cyc,
+                "valu_wave_insts_per_column": prof["valu_insts_per_column"], "clock_ghz": prof["clock_ghz"],
+                "lds_pipe_busy_frac": lds_busy, "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
+                "wait_any_share": prof.get("wait_any_share"),
+                "note": "live wave-instruction rate (committed SQ_INSTS_VALU per column x this run's columns/s) x cycles per instruction / "
+                        "(1024 SIMDs x the profiled clock); lds_pipe_busy_frac = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles) of the profiled "
+                        "launch (binary64 kernels: the 4-cycle figure is the fma/add/mul rate, so frac is a lower bound of pipe time)",
+                "source": prof["file"]}
+        else:
+            line["roofline_valu"] = None
 
         if world == 1 and args.workload == "batch64" and not args.no_configs:
             # ---- the other named BASELINE configs, measured beside the headline on the same engine and input
@@ -650,16 +767,18 @@ def main():
             measure("configs[0] shape: 1 stream, FFT 1024, hop 256, reassignment OFF", 1, 1 << 20, 1024, 256, False, 50)
             one = measure("configs[1]: 1 stream, FFT 4096, hop 256, reassignment ON", 1, L, 4096, 256, True, 50)
             c4 = measure("configs[4]: 64 streams, FFT 16384, hop 512, reassignment ON", 64, L, 16384, 512, True, 3)
-            p4, f4 = profile_for("n16384")
+            p4, f4 = profile_for("n16384", lib_sha)
             if p4:
                 c4["roofline"]["traffic"] = p4.get("hbm_bytes_per_launch") if f4 else None
                 c4["roofline"]["traffic_source"] = f"{p4['file']}{'' if f4 else ' (STALE: kernels changed since, withheld)'}"
             measure("64 streams, FFT 4096, hop 256, reassignment OFF", 64, L, 4096, 256, False, 3)
             measure("64 streams, FFT 1024, hop 256, reassignment ON", 64, 1 << 20, 1024, 256, True, 5)
             # EXACT mode (binary64 + 64-bit fixed point: indices equal to a float64 implementation, bytes reproducible) on
-            # a second engine: configs[2] on 16 of the 64 streams (the record workspace is 0.4 GB per stream) and configs[4]
+            # a second engine: configs[2] itself (64 streams; one fused kernel since round 4, no workspace) and configs[4] on
+            # 8 streams (N = 16384 still runs the two-kernel records path: 1.2 GB of workspace per stream)
             xeng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT)
-            for name, Sx, nx, hx, reps in (("EXACT mode, configs[2] shape: 16 streams, FFT 4096, hop 256, reassignment ON", 16, 4096, 256, 3),
+            xname = "EXACT mode, configs[2]: 64 streams, FFT 4096, hop 256, reassignment ON"
+            for name, Sx, nx, hx, reps in ((xname, 64, 4096, 256, 3),
                                            ("EXACT mode, configs[4] shape: 8 streams, FFT 16384, hop 512, reassignment ON", 8, 16384, 512, 2)):
                 Cx = emspec.num_columns(L, nx, hx)
                 px = pcm[:Sx].contiguous()
@@ -667,7 +786,12 @@ def main():
                 ixx = idx.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
                 ms = time_launches(lambda: xeng.batch_device(px, nx, hx, True, db=dbx, index=ixx, stream=cur), cur, reps)
                 cfgs[name] = {"columns_per_s": Sx * Cx / (ms * 1e-3), "columns_per_launch": Sx * Cx, "kernel_ms": ms,
-                              "dtype": "f64", "roofline": roofline(Sx * Cx, 4 * hx + 5 * R, ms)}
+                              "dtype": "f64", "fused_kernel": xeng.fused(nx, hx, True), "roofline": roofline(Sx * Cx, 4 * hx + 5 * R, ms)}
+            px_, fx_ = profile_for("exact64", lib_sha)
+            if px_:
+                cfgs[xname]["roofline"]["traffic"] = px_.get("hbm_bytes_per_launch") if fx_ else None
+                cfgs[xname]["roofline"]["traffic_source"] = f"{px_['file']}{'' if fx_ else ' (STALE: kernels changed since, withheld)'}"
+            xeng.device_status()      # a protocol error of the fused kernels' bounded waits would surface here
             xeng.close()
             if not args.no_cpu_baseline:
                 # the binary64 bit model (oracle/emspec_exact.c, scalar C, one thread) on a bounded sample: the CPU figure beside
@@ -676,7 +800,7 @@ def main():
                 from emspec import synth as _synth
                 xs = _synth.streams(1, 4096 + 256 * 1023)
                 t0 = time.perf_counter(); O.batch_exact(O.make_cfg(4096, 256, True), xs, want=("db", "index"), threads=1); dtx = time.perf_counter() - t0
-                cfgs["EXACT mode, configs[2] shape: 16 streams, FFT 4096, hop 256, reassignment ON"]["cpu_port_columns_per_s_one_thread"] = 1024 / dtx
+                cfgs[xname]["cpu_port_columns_per_s_one_thread"] = 1024 / dtx
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
 
@@ -702,7 +826,7 @@ def main():
             pd = roofline(Sd * Cd, bpc, dms, "algorithmic bytes = 4*hop in + 12*(N/2+1) per-bin dump out; 16 streams x 2^20 samples")
             pd["columns_per_s"] = Sd * Cd / (dms * 1e-3)
             pd["kernel"] = "parity dump (emspec_parity_dump_device)"
-            pp, pf = profile_for("paritydump")
+            pp, pf = profile_for("paritydump", lib_sha)
             pd["traffic"] = pp.get("hbm_bytes_per_launch") if (pp and pf) else None
             if pp:
                 pd["traffic_source"] = f"{pp['file']}{'' if pf else ' (STALE, withheld)'}"
@@ -715,9 +839,12 @@ def main():
             line["cpu_baseline"] = None
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
+    eng.device_status()           # raises if a kernel flagged a protocol error during the run (the line above would be invalid)
     if dist_on:
+        dog.arm(120.0, "the final barrier")
         dist.barrier()
         dist.destroy_process_group()
+        dog.disarm()
     eng.close()
 
 

@@ -305,9 +305,32 @@ void emspec_destroy(emspec_engine* e) {
 }
 
 const char* emspec_last_error(const emspec_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+int32_t emspec_mode(const emspec_engine* e) { return e ? e->cfg.mode : -1; }
+#ifndef EMSPEC_SOURCES_SHA
+#define EMSPEC_SOURCES_SHA "unknown"
+#endif
+#define EMSPEC_STR2(x) #x
+#define EMSPEC_STR(x) EMSPEC_STR2(x)
+const char* emspec_build_info(void) { return "emspec abi=" EMSPEC_STR(EMSPEC_ABI_VERSION) " sources=" EMSPEC_SOURCES_SHA " arch=gfx950"; }
+int emspec_device_status(emspec_engine* e) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    const int w = read_kernel_error(true);
+    if (w != 0) return fail(e, EMSPEC_ERR_HIP, w < 0 ? "the device's kernel error word could not be read"
+                                                  : "a kernel's bounded wait timed out (protocol error): the results of the launches since the last check are invalid");
+    return EMSPEC_OK;
+}
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign) {
-    return e && !e->exact() && fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
+    if (!e || n < 1 || hop < 1) return 0;
+    if (e->exact()) {   // only the shape decides (exact_fused_supported reads rows and D)
+        ExactPlanDev pd{};
+        pd.rows = e->cfg.rows;
+        pd.D = latency(n, hop, reassign);
+        return exact_fused_supported(n, pd) ? 1 : 0;
+    }
+    return fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
 }
 
 static void drop_plans(emspec_engine* e) {
@@ -699,6 +722,7 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     HIPCHK(e, herr);
     HIPCHK(e, s1);
     HIPCHK(e, s2);
+    if (read_kernel_error(true) > 0) return fail(e, EMSPEC_ERR_HIP, "a kernel's bounded wait timed out (protocol error): results invalid");
     return EMSPEC_OK;
 }
 

@@ -18,8 +18,11 @@
 
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -47,6 +50,7 @@ struct emspec_comm_state {
     std::vector<uint64_t> packed_layout;
     uint64_t* h_dir = nullptr;                               // page-locked directories (kDirSlots of them, used in rotation: the
     unsigned dir_next = 0;                                   //  copy to the head of gathered_dev is still in flight at return)
+    double timeout_s = 120.0;                                // bound on the one host wait of a gather (0: wait for ever)
 };
 static constexpr unsigned kDirSlots = 8;
 
@@ -58,6 +62,27 @@ namespace {
         if (_r != ncclSuccess)                                                                \
             return fail((e), EMSPEC_ERR_COMM, std::string(#call) + ": " + ncclGetErrorString(_r)); \
     } while (0)
+
+// A communicator that returned an error, or whose peers did not show up, is in an undefined state: tear it down
+// (ncclCommAbort also ends the kernels it still has in flight) so that later calls fail at once with EMSPEC_ERR_STATE
+// instead of blocking.
+void abort_comm(emspec_comm_state* c) {
+    if (c && c->comm) {
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+    }
+}
+#define NCCLCHK_ABORT(e, c, call)                                                             \
+    do {                                                                                      \
+        ncclResult_t _r = (call);                                                             \
+        if (_r != ncclSuccess) {                                                              \
+            abort_comm(c);                                                                    \
+            return fail((e), EMSPEC_ERR_COMM, std::string(#call) + ": " + ncclGetErrorString(_r) + " (communicator aborted)"); \
+        }                                                                                     \
+    } while (0)
+
+// the rank-local part of a gather that can fail before the size exchange
+constexpr uint64_t kRankFailed = ~0ull;   // in the (bytes, columns) pair of the size exchange: "this rank cannot take part"
 
 int ensure_wire_buffers(emspec_engine* e, emspec_comm_state* c, int64_t columns) {
     int rc;
@@ -124,6 +149,14 @@ int emspec_comm_destroy(emspec_engine* e) {
     return EMSPEC_OK;
 }
 
+int emspec_comm_set_timeout(emspec_engine* e, double seconds) {
+    if (!e || !(seconds >= 0.0)) return fail(e, EMSPEC_ERR_INVALID_ARG, "seconds must be >= 0");
+    emspec_comm_state* c = state(e);
+    if (!c) return fail(e, EMSPEC_ERR_OUT_OF_MEMORY, "out of host memory");
+    c->timeout_s = seconds;
+    return EMSPEC_OK;
+}
+
 int32_t emspec_comm_rank(const emspec_engine* e) { return e && e->comm && e->comm->comm ? e->comm->rank : -1; }
 int32_t emspec_comm_world(const emspec_engine* e) { return e && e->comm && e->comm->comm ? e->comm->world : 0; }
 
@@ -176,12 +209,9 @@ int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_b
 
 int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t columns, int32_t root, uint8_t* gathered_dev,
                           int64_t gathered_capacity, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent) {
-    if (!e || !index_dev || columns < 1) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument / no columns");
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
     emspec_comm_state* c = e->comm;
-    if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first");
-    if (root < 0 || root >= c->world) return fail(e, EMSPEC_ERR_INVALID_ARG, "root out of range");
-    if (c->rank == root && !gathered_dev) return fail(e, EMSPEC_ERR_INVALID_ARG, "the root needs the gathered buffer");
-    if ((uint64_t)columns * (uint64_t)e->cfg.rows >= (1ull << 32)) return fail(e, EMSPEC_ERR_INVALID_ARG, "at most 2^32 cells per call");
+    if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first (or it was aborted after an error)");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const int R = e->cfg.rows, world = c->world, me = c->rank;
@@ -191,27 +221,65 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     const size_t col_bytes = (size_t)columns * R;
     const bool i_send = !is_root || loopback;
     const bool i_pack = i_send || packed;                          // packed: the root's own columns become an image too
-    int rc;
     if (wire_bytes_sent) *wire_bytes_sent = 0;
-    c->h_sizes[2 * world] = (uint64_t)columns;   // page-locked: read by the async copy below
 
+    // ---- everything that can fail on THIS rank alone happens before the size exchange, and a failure does not return:
+    // the rank still enters the all-gather, with kRankFailed in place of its image size, so that every rank learns of it
+    // in the same collective and all of them return together (a rank that simply returned would leave its peers blocked
+    // in the all-gather for ever).
+    int local_rc = EMSPEC_OK;
+    std::string local_msg;
+    auto local_fail = [&](int code, const std::string& msg) { if (local_rc == EMSPEC_OK) { local_rc = code; local_msg = msg; } };
+    if (!index_dev || columns < 1) local_fail(EMSPEC_ERR_INVALID_ARG, "null argument / no columns");
+    else if (root < 0 || root >= world) local_fail(EMSPEC_ERR_INVALID_ARG, "root out of range");
+    else if (is_root && !gathered_dev) local_fail(EMSPEC_ERR_INVALID_ARG, "the root needs the gathered buffer");
+    else if ((uint64_t)columns * (uint64_t)R >= (1ull << 32)) local_fail(EMSPEC_ERR_INVALID_ARG, "at most 2^32 cells per call");
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_GATHER_FAIL_RANK"))        // test hook: this rank "runs out of memory" before the exchange
+        if (atoi(ev) == me) local_fail(EMSPEC_ERR_OUT_OF_MEMORY, "injected failure before the size exchange (EMSPEC_GATHER_FAIL_RANK)");
+#endif
     // ---- this rank's wire image
-    uint64_t* d_total = nullptr;
-    if (i_pack) {
-        if ((rc = ensure_wire_buffers(e, c, columns))) return rc;
-        HIPCHK(e, launch_wire_pack(index_dev, columns, R, c->d_wire, c->d_scratch, st));
+    uint64_t* d_total = c->d_sizes + 2 * (size_t)world;            // spare pair behind the gathered sizes: used when nothing was packed
+    if (local_rc == EMSPEC_OK) {
+        int rc = i_pack ? ensure_wire_buffers(e, c, columns) : grow(e, &c->d_scratch, &c->scratch_bytes, wire_scratch_bytes(columns));
+        if (rc != EMSPEC_OK) local_fail(rc, e->err);
+    }
+    if (local_rc == EMSPEC_OK && i_pack) {
+        const hipError_t he = launch_wire_pack(index_dev, columns, R, c->d_wire, c->d_scratch, st);
+        if (he != hipSuccess) local_fail(EMSPEC_ERR_HIP, std::string("wire pack launch: ") + hipGetErrorString(he));
+    }
+    if (local_rc == EMSPEC_OK) {
         d_total = wire_total_ptr(c->d_scratch, columns);
+        if (!i_pack) HIPCHK(e, hipMemsetAsync(d_total, 0, sizeof(uint64_t), st));   // the root sends nothing
+        c->h_sizes[2 * world] = (uint64_t)columns;                 // page-locked: read by the async copy below
+        HIPCHK(e, hipMemcpyAsync(d_total + 1, &c->h_sizes[2 * world], sizeof(uint64_t), hipMemcpyHostToDevice, st));
     } else {
-        if ((rc = grow(e, &c->d_scratch, &c->scratch_bytes, wire_scratch_bytes(columns)))) return rc;
-        d_total = wire_total_ptr(c->d_scratch, columns);
-        HIPCHK(e, hipMemsetAsync(d_total, 0, sizeof(uint64_t), st));   // the root sends nothing
+        c->h_sizes[2 * world] = kRankFailed;
+        c->h_sizes[2 * world + 1] = 0;
+        HIPCHK(e, hipMemcpyAsync(d_total, &c->h_sizes[2 * world], 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     }
     // ---- everybody learns everybody's image size and column count (RCCL counts must match on both sides of a
     // send/recv; shards may differ in size: a host that gives the root fewer streams balances its extra expand work)
-    HIPCHK(e, hipMemcpyAsync(d_total + 1, &c->h_sizes[2 * world], sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    NCCLCHK(e, ncclAllGather(d_total, c->d_sizes, 2, ncclUint64, c->comm, st));
+    NCCLCHK_ABORT(e, c, ncclAllGather(d_total, c->d_sizes, 2, ncclUint64, c->comm, st));
     HIPCHK(e, hipMemcpyAsync(c->h_sizes, c->d_sizes, sizeof(uint64_t) * 2 * (size_t)world, hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipStreamSynchronize(st));
+    {   // the one host wait of the call, bounded: a peer that never enters the collective must not hang this rank for ever
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(st)) == hipErrorNotReady) {
+            if (c->timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+                abort_comm(c);
+                return fail(e, EMSPEC_ERR_COMM, "the size exchange of the gather did not complete within the communicator's timeout "
+                                                "(a peer rank is missing); communicator aborted");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        HIPCHK(e, q);
+    }
+    if (local_rc != EMSPEC_OK) return fail(e, local_rc, local_msg);          // (the peers return EMSPEC_ERR_COMM below)
+    for (int r = 0; r < world; ++r)
+        if (c->h_sizes[2 * r] == kRankFailed)
+            return fail(e, EMSPEC_ERR_COMM, "rank " + std::to_string(r) + " failed before the exchange: no columns were transferred");
+    int rc;
     for (int r = 0; r < world; ++r) {
         const uint64_t bytes_r = c->h_sizes[2 * r], cols_r = c->h_sizes[2 * r + 1];
         if (cols_r < 1 || cols_r * (uint64_t)R >= (1ull << 32) || bytes_r > (uint64_t)wire_bound_bytes((int64_t)cols_r, R))
@@ -238,7 +306,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
         if (fits) recv_base = gathered_dev + dir_bytes;            // the images land where they stay
         else if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc; else recv_base = c->d_recv;
     }
-    NCCLCHK(e, ncclGroupStart());
+    NCCLCHK_ABORT(e, c, ncclGroupStart());
     ncclResult_t nr = ncclSuccess;
     if (i_send && c->h_sizes[2 * me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[2 * me], ncclUint8, root, c->comm, st);
     if (is_root)
@@ -246,8 +314,10 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
             if (c->h_sizes[2 * r] > 0 && (r != me || loopback))
                 nr = ncclRecv(recv_base + off[r], (size_t)c->h_sizes[2 * r], ncclUint8, r, c->comm, st);
     const ncclResult_t ge = ncclGroupEnd();
-    if (nr != ncclSuccess) return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr));
-    NCCLCHK(e, ge);
+    if (nr != ncclSuccess || ge != ncclSuccess) {
+        abort_comm(c);
+        return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr != ncclSuccess ? nr : ge) + " (communicator aborted)");
+    }
 
     if (!fits) return fail(e, EMSPEC_ERR_INVALID_ARG, "the gathered buffer is smaller than the shards the ranks announced");
 

@@ -60,9 +60,11 @@ bool exact_fused_supported(int n, const ExactPlanDev& pl);
 hipError_t launch_exact_fused(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
                               int64_t L, int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
                               unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
-int exact_fused_read_errflag();   // non-zero: a bounded spin of the fused exact kernel timed out on this device (results invalid)
 hipError_t launch_exact_finalize(const unsigned long long* cells, int64_t ncells, const ExactDbMap& m, const uint8_t* lut,
                                  float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
+
+// the device word a kernel raises when a bounded wait times out (kernels.hip: g_kernel_error); -1 if it cannot be read
+int read_kernel_error(bool clear);
 
 bool supported_fft(int n);
 

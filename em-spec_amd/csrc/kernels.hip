@@ -37,6 +37,19 @@ static hipError_t allow_max_lds(const void* fn) {
     if (e == hipSuccess) done.insert({dev, fn});
     return e;
 }
+// Device word raised by a kernel whose bounded wait timed out (the arrival-counter polls of the fused kernels: a protocol
+// error - every wave arrives before it polls, so a timeout cannot happen in a correct build - after which the results
+// are invalid).  A symbol of the code object, so no kernel carries a pointer for it; emspec_device_status reads it.
+__device__ int g_kernel_error = 0;
+int read_kernel_error(bool clear) {
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_kernel_error), sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (v && clear) {
+        const int zero = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kernel_error), &zero, sizeof(int));
+    }
+    return v;
+}
 // compute units of the current device (grid sizing: workgroups per launch are counted in rounds of CUs)
 int device_cus() {
     static std::mutex mu;

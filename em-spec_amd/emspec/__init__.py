@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(ROOT, "libemspec.so")
 # EMSPEC_* environment switches.  Tools and the tests that probe internals load this one; the product never does.
 DIAG_LIB_PATH = os.path.join(ROOT, "libemspec_diag.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_STATE, ERR_COMM = -1, -2, -3, -4, -5, -6
 MODE_FAST, MODE_EXACT = 0, 1
@@ -35,7 +35,8 @@ SYMBOLS = [
     "emspec_push_samples", "emspec_push_columns", "emspec_warped_edges_hz", "emspec_make_colormap",
     "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
     "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
-    "emspec_parity_dump_exact", "emspec_gather_packed_layout",
+    "emspec_parity_dump_exact", "emspec_gather_packed_layout", "emspec_mode", "emspec_build_info", "emspec_device_status",
+    "emspec_comm_set_timeout",
 ]
 
 
@@ -126,8 +127,19 @@ def load(diag=False):
     lib.emspec_wire_bound.argtypes = [C.c_int64, C.c_int32]
     lib.emspec_wire_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
     lib.emspec_wire_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.emspec_mode.argtypes = [C.c_void_p]
+    lib.emspec_mode.restype = C.c_int32
+    lib.emspec_build_info.argtypes = []
+    lib.emspec_build_info.restype = C.c_char_p
+    lib.emspec_device_status.argtypes = [C.c_void_p]
+    lib.emspec_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
     _libs[diag] = lib
     return lib
+
+
+def build_info(diag=False):
+    """What the loaded library was built from: 'emspec abi=2 sources=<sha16> arch=gfx950' (emspec_build_info)."""
+    return load(diag).emspec_build_info().decode()
 
 
 class PinnedArray:
@@ -225,6 +237,11 @@ class Engine:
             raise EmspecError(rc, self._lib.emspec_last_error(None).decode())
         self._h = h
         self.rows = int(self.cfg.rows)
+        # the library must run the mode that was asked for (a version-1 library ignored the field: include/emspec.h)
+        if self._lib.emspec_mode(h) != int(self.cfg.mode):
+            self._lib.emspec_destroy(h)
+            self._h = None
+            raise EmspecError(ERR_STATE, "the library did not honour the requested arithmetic mode")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -246,6 +263,14 @@ class Engine:
     def _chk(self, rc):
         if rc != OK:
             raise EmspecError(rc, self._lib.emspec_last_error(self._h).decode())
+
+    @property
+    def mode(self):
+        return int(self._lib.emspec_mode(self._h))
+
+    def device_status(self):
+        """Synchronise the device and raise if a kernel flagged a protocol error (emspec_device_status)."""
+        self._chk(self._lib.emspec_device_status(self._h))
 
     @property
     def arch(self):
@@ -320,6 +345,10 @@ class Engine:
 
     def comm_destroy(self):
         self._chk(self._lib.emspec_comm_destroy(self._h))
+
+    def comm_set_timeout(self, seconds):
+        """Bound on the host wait inside gather_columns (the size exchange); 0 = none.  On expiry the communicator is aborted."""
+        self._chk(self._lib.emspec_comm_set_timeout(self._h, float(seconds)))
 
     @property
     def comm_rank(self):

@@ -117,6 +117,11 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     emspec_engine* e = NULL;
     int rc = emspec_create(&cfg, &e);
     if (rc != EMSPEC_OK) return throw_status(env, NULL, rc);
+    if (emspec_mode(e) != cfg.mode) {   /* a library that ignores the mode field must not pass for an exact engine */
+        emspec_destroy(e);
+        napi_throw_error(env, "EMSPEC_ERR_STATE", "the library did not honour the requested arithmetic mode");
+        return NULL;
+    }
     handle_t* h = (handle_t*)malloc(sizeof(handle_t));
     if (!h) { emspec_destroy(e); napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
     h->e = e;
@@ -558,6 +563,29 @@ static napi_value BatchGather(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* buildInfo() -> "emspec abi=2 sources=<sha16> arch=gfx950" */
+static napi_value BuildInfo(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value r;
+    NAPI_OK_OR_RETURN(env, napi_create_string_utf8(env, emspec_build_info(), NAPI_AUTO_LENGTH, &r));
+    return r;
+}
+
+/* deviceStatus(handle): synchronise the device; throws when a kernel flagged a protocol error */
+static napi_value DeviceStatus(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = NULL;
+    if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->e) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "engine handle expected");
+        return NULL;
+    }
+    int rc = emspec_device_status(h->e);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_get_undefined(env, &r));
+    return r;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     napi_property_descriptor props[] = {
         {"create", NULL, Create, NULL, NULL, NULL, napi_default, NULL},
@@ -582,6 +610,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"commUniqueId", NULL, CommUniqueId, NULL, NULL, NULL, napi_default, NULL},
         {"commInit", NULL, CommInit, NULL, NULL, NULL, napi_default, NULL},
         {"batchGather", NULL, BatchGather, NULL, NULL, NULL, napi_default, NULL},
+        {"buildInfo", NULL, BuildInfo, NULL, NULL, NULL, napi_default, NULL},
+        {"deviceStatus", NULL, DeviceStatus, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
     return exports;

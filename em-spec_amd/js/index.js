@@ -71,6 +71,9 @@ class Engine {
     return native.batchAsync(this._h, pcm, S, L, fftSize, hop, !!reassign, out.db, out.rgba, out.index);
   }
 
+  /** Synchronise the device and throw if a kernel flagged a protocol error since the last check (emspec_device_status). */
+  deviceStatus() { native.deviceStatus(this._h); }
+
   /** Multi-GPU (one node process per GPU): join the gather communicator.  id = commUniqueId() of rank 0, handed over by
    *  the host's own channel (IPC, a file); collective over all `world` rank processes. */
   commInit(id, rank, world) { native.commInit(this._h, id, rank, world); this.commRank = rank; this.commWorld = world; }
@@ -155,4 +158,6 @@ module.exports = {
   commUniqueId: native.commUniqueId,
   numColumns: native.numColumns,
   latencyColumns: native.latencyColumns,
+  /** 'emspec abi=2 sources=<sha16> arch=gfx950': what the loaded libemspec was built from. */
+  buildInfo: native.buildInfo,
 };

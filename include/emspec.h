@@ -35,7 +35,10 @@
 extern "C" {
 #endif
 
-#define EMSPEC_ABI_VERSION 1
+/* 2 (round 4): emspec_config.mode is read (it was a reserved, ignored field in version 1, so a version-1 library would
+ * silently run an EXACT-mode request in float32: emspec_create now rejects the mismatch); added emspec_mode,
+ * emspec_build_info, emspec_device_status, emspec_comm_set_timeout; emspec_uses_fused answers for EXACT-mode engines too. */
+#define EMSPEC_ABI_VERSION 2
 
 typedef enum emspec_status {
     EMSPEC_OK = 0,
@@ -84,7 +87,7 @@ typedef struct emspec_config {
  *                      with a float64 implementation of the three-window method on every bin, and dB / palette index /
  *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes.  Inputs must stay
  *                      within |x| <= 4 (the fixed point covers 2^11 full-scale-sine powers per cell).  Same entry points;
- *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 3.2x slower than the fast mode at N = 4096.
+ *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 2.6x slower than the fast mode at N = 4096.
  */
 #define EMSPEC_MODE_FAST 0
 #define EMSPEC_MODE_EXACT 1
@@ -106,6 +109,23 @@ int emspec_default_config(emspec_config* cfg);
  * renderer's first computeSpectrogramColumn call. */
 int emspec_create(const emspec_config* cfg, emspec_engine** out_engine);
 void emspec_destroy(emspec_engine* e);
+
+/* The arithmetic mode this engine really runs in (EMSPEC_MODE_FAST / EMSPEC_MODE_EXACT), -1 for NULL: lets a binding
+ * assert that a request for bit-exact results was honoured. */
+int32_t emspec_mode(const emspec_engine* e);
+
+/* What this library was built from: "emspec abi=2 sources=<16 hex digits> arch=gfx950", the digits being the sha1 of the
+ * kernel / C-ABI sources (tools/sources_sha.py) taken when the library was compiled.  bench.py quotes profile-derived
+ * numbers only while this, the source tree and the profile agree.  Never NULL; static storage. */
+const char* emspec_build_info(void);
+
+/* Synchronises the engine's device and reports what its kernels may have flagged since the last call: EMSPEC_OK, or
+ * EMSPEC_ERR_HIP when a kernel's bounded wait timed out (the fused kernels order some phases with arrival counters in
+ * LDS; every wait is bounded so that a protocol error cannot hang the device - the results of that launch are then
+ * invalid) or the device reports an asynchronous error.  The synchronous batch entry points (emspec_batch,
+ * emspec_batch_gather) check it themselves; callers of emspec_batch_device call this after their own stream
+ * synchronisation when they want the check (the streaming calls run kernels without such waits). */
+int emspec_device_status(emspec_engine* e);
 
 /* Last error message of this engine (or of the failed emspec_create when
  * e == NULL).  Never NULL; valid until the next call on the same thread. */
@@ -285,6 +305,10 @@ int emspec_parity_dump_device(emspec_engine* e, const float* pcm_dev, int32_t S,
 int emspec_comm_unique_id(uint8_t* id_out /* [EMSPEC_COMM_ID_BYTES] */);
 int emspec_comm_init(emspec_engine* e, const uint8_t* id /* [EMSPEC_COMM_ID_BYTES] */, int32_t rank, int32_t world);
 int emspec_comm_destroy(emspec_engine* e);
+/* Bound (seconds, default 120; 0 = none) on the one host wait inside emspec_gather_columns - the size exchange every rank
+ * must enter.  When it expires the communicator is aborted (ncclCommAbort) and the call returns EMSPEC_ERR_COMM: a rank
+ * that died does not hang its peers for ever.  May be called before emspec_comm_init. */
+int emspec_comm_set_timeout(emspec_engine* e, double seconds);
 int32_t emspec_comm_rank(const emspec_engine* e);    /* -1 without a communicator */
 int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator */
 
@@ -300,11 +324,17 @@ int32_t emspec_comm_world(const emspec_engine* e);   /* 0 without a communicator
  * and must be known on the host before the transfers can be posted): enqueue the next chunk's
  * emspec_batch_device on another stream BEFORE calling it, and the gather overlaps that compute.
  * *wire_bytes_sent (optional) receives the size of this rank's packed image (0 on the root).
+ * Failure semantics: whatever can fail on one rank alone (arguments, device memory, the pack launch) is detected before the
+ * size exchange, and that rank still enters the exchange with an error mark in place of its size - so ALL ranks return
+ * from the same call: the failing rank with its own error, the others with EMSPEC_ERR_COMM, nothing transferred, the
+ * communicator still usable.  An RCCL error, or a peer that does not show up within the timeout, aborts the communicator
+ * (later calls: EMSPEC_ERR_STATE).
  * flags: EMSPEC_GATHER_LOOPBACK makes the root's own columns take the wire as well (self send/recv; exercising
  * the whole path on a single GPU).
  * EMSPEC_GATHER_PACKED: the root does NOT expand: gathered_dev receives a directory (per rank: u64 offset, u64 image bytes,
  * u64 columns, u64 0; padded to 256 B) followed by every rank's wire image (the root's own included), 256-byte aligned,
- * in rank order; capacity needed: 256 * (world + 1) + sum over ranks of emspec_wire_bound(columns_r, rows).  Nothing is
+ * in rank order; capacity needed: align256(32 * world) + sum over ranks of align256(emspec_wire_bound(columns_r, rows))
+ * (align256(x) = x rounded up to a multiple of 256).  Nothing is
  * lost - emspec_wire_unpack(gathered_dev + offset, bytes, columns, ...) expands any rank's block on demand (the layout
  * is also available on the host: emspec_gather_packed_layout) - and the root, which otherwise expands world-1 images
  * per gather beside its own column kernel, only receives.
@@ -353,8 +383,9 @@ int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twi
  * (n = 1024, 2048, 4096 at any hop whose column ring fits in LDS; n = 8192 at
  * hop 512 or 1024; n = 16384 at any hop whose ring has at most 33 slots of 1024
  * rows, e.g. hop 512; at most 1024 rows), 0 if the generic two-kernel path
- * (per-bin records + LDS tile / walking-ring scatter) - always 0 for an
- * EXACT-mode engine.  Same results either way. */
+ * (per-bin records + LDS tile / walking-ring scatter).  EXACT-mode engines:
+ * 1 for n = 4096 at any hop whose u64 column ring fits in LDS beside the tables
+ * (hop >= 228 at 1024 rows: exact_fused.hip.inc), else 0.  Same results either way. */
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign);
 
 /* Name of the device the engine runs on, e.g. "gfx950". */

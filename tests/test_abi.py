@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -59,7 +60,7 @@ def test_pure_functions():
     assert emspec.latency_columns(16384, 512, True) == 16
     assert emspec.latency_columns(4096, 256, False) == 0
     cfg = emspec.default_config()
-    assert (cfg.rows, cfg.abi_version) == (1024, 1)
+    assert (cfg.rows, cfg.abi_version) == (1024, 2)
     assert cfg.sample_rate == 48000.0 and cfg.fmin_hz == 20.0
 
 
@@ -79,6 +80,30 @@ def test_create_rejects_bad_config():
     cfg = emspec.default_config(abi_version=99)
     assert lib.emspec_create(C.byref(cfg), C.byref(h)) == emspec.ERR_INVALID_ARG
     assert b"abi_version" in lib.emspec_last_error(None)
+
+
+def test_build_info_carries_the_sources_sha():
+    """emspec_build_info: the sha1 of the kernel sources the LOADED library was compiled from (tools/sources_sha.py, compiled
+    in by the Makefile) - what bench.py compares with the tree and the profile before it quotes a counter."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import sources_sha
+    finally:
+        sys.path.pop(0)
+    for diag in (False, True):
+        info = emspec.build_info(diag)
+        assert info.startswith("emspec abi=2 sources=") and info.endswith(" arch=gfx950"), info
+        assert f"sources={sources_sha.sources_sha()}" in info, (info, "the in-tree .so is older than the sources: rebuild")
+    assert emspec.load().emspec_mode(None) == -1
+
+
+def test_version_1_clients_are_rejected():
+    """ABI 2 reads emspec_config.mode (reserved and ignored in version 1): a client built against the old header must
+    fail emspec_create instead of getting an engine whose mode field was never initialised."""
+    lib = emspec.load()
+    h = C.c_void_p()
+    cfg = emspec.default_config(abi_version=1)
+    assert lib.emspec_create(C.byref(cfg), C.byref(h)) == emspec.ERR_INVALID_ARG
 
 
 def test_product_does_not_link_the_oracle():

@@ -118,3 +118,36 @@ def test_rccl_gather_one_rank_loopback():
         with pytest.raises(emspec.EmspecError) as ei:
             e2.gather_columns(torch.zeros((4, 1024), dtype=torch.uint8, device=dev), out=torch.zeros((1, 4, 1024), dtype=torch.uint8, device=dev))
         assert ei.value.code == emspec.ERR_STATE
+
+
+@pytest.mark.gpu
+def test_gather_failure_before_the_exchange_is_collective(monkeypatch):
+    """A rank that fails before the size exchange (out of memory, bad arguments) still enters the all-gather with an error
+    mark, so every rank returns from the same call (round 3 returned on the failing rank alone and left its peers blocked in
+    the collective).  One-rank RCCL form: the injected failure travels through the all-gather, the call returns the rank's
+    own error, nothing is written, and the communicator is still usable afterwards."""
+    n, hop, S, frames = 4096, 256, 2, 40
+    pcm = synth.streams(S, n + hop * (frames - 1))
+    dev = torch.device("cuda", 0)
+    with emspec.Engine(diag=True) as e:
+        e.comm_set_timeout(30.0)
+        e.comm_init(emspec.comm_unique_id(), 0, 1)
+        idx = torch.empty((S, frames, e.rows), dtype=torch.uint8, device=dev)
+        e.batch_device(torch.from_numpy(pcm).to(dev), n, hop, True, index=idx)
+        out = torch.full((1, S, frames, e.rows), 0xEE, dtype=torch.uint8, device=dev)
+        monkeypatch.setenv("EMSPEC_GATHER_FAIL_RANK", "0")
+        with pytest.raises(emspec.EmspecError) as ei:
+            e.gather_columns(idx, root=0, out=out, loopback=True)
+        assert ei.value.code == emspec.ERR_OOM and "injected" in str(ei.value)
+        torch.cuda.synchronize()
+        assert bool((out == 0xEE).all())
+        # bad arguments on one rank take the same road (they used to return before the collective)
+        monkeypatch.delenv("EMSPEC_GATHER_FAIL_RANK")
+        with pytest.raises(emspec.EmspecError) as ei:
+            e.gather_columns(idx, root=3, out=out, loopback=True)
+        assert ei.value.code == emspec.ERR_INVALID_ARG
+        # ... and the communicator survived both
+        assert e.gather_columns(idx, root=0, out=out, loopback=True) > 32
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], idx)
+        assert e.comm_world == 1

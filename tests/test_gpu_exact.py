@@ -226,7 +226,10 @@ def test_exact_mode_guards(xengine, engine):
     with pytest.raises(emspec.EmspecError) as ei:
         engine.parity_dump_exact(pcm, 1024, 256, True, 0, 4)
     assert ei.value.code == emspec.ERR_STATE
-    assert not xengine.fused(4096, 256, True)
+    # emspec_uses_fused answers for EXACT engines since ABI 2: one kernel at N = 4096 when the u64 ring fits, records otherwise
+    assert xengine.fused(4096, 256, True) and xengine.fused(4096, 1024, False) and not xengine.fused(4096, 128, True)
+    assert not xengine.fused(16384, 512, True) and not xengine.fused(1024, 256, True)
+    assert xengine.mode == emspec.MODE_EXACT and engine.mode == emspec.MODE_FAST
     with pytest.raises(emspec.EmspecError):
         emspec.Engine(mode=7)
 

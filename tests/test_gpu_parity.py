@@ -794,17 +794,38 @@ def test_bench_one_rank_with_process_group_rehearsal():
     # the root's expand costs
     g = b["gather"]
     assert g["rccl_world"] == 1 and g["streams_per_rank"] == [8] and len(g["kernel_ms_per_rank"]) == 1 and g["kernel_ms_per_rank"][0] > 0
-    assert g["root_expand_ms_standalone"] is not None and g["root_expand_ms_standalone"] >= 0 and g["root_keeps_images_packed"] is False
-    assert g["packed_columns_per_s"] > 0        # the same job with the images kept packed on the root, measured after the timed run
-    # ... and the packed-on-root form of the same run (EMSPEC_GATHER_PACKED: the root only receives)
-    r = subprocess.run(cmd + ["--gather-packed"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29541"), cwd=root)
+    # (since round 4 the timed form keeps the images packed on the root; the expanding form runs beside it)
+    assert g["root_expand_ms_standalone"] is not None and g["root_expand_ms_standalone"] >= 0 and g["root_keeps_images_packed"] is True
+    assert g["expanding_columns_per_s"] > 0 and g["packed_columns_per_s"] is None and g["step_deadline_s"] >= 30.0
+    # ... and the expanding form as the timed one (the root turns every image back into plain arrays)
+    r = subprocess.run(cmd + ["--gather-expand"], capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29541"), cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     p = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert p["gather"]["root_keeps_images_packed"] is True and 32 < p["gather"]["wire_bytes_per_column"] < 768 and p["value"] > 0
+    assert p["gather"]["root_keeps_images_packed"] is False and 32 < p["gather"]["wire_bytes_per_column"] < 768 and p["value"] > 0
+    assert p["gather"]["packed_columns_per_s"] > 0
     # a failing rank ends the job with a non-zero exit
     r = subprocess.run(cmd[:2] + ["--gather", "dist-loopback", "--streams", "2", "--log2-samples", "11", "--no-cpu-baseline", "--no-configs"],
                        capture_output=True, text=True, timeout=300, env=dict(env, MASTER_PORT="29543"), cwd=root)
     assert r.returncode != 0
+
+
+def test_bench_watchdog_ends_a_job_whose_rank_stops():
+    """A rank that stops making progress mid-run (here: rank 1 sleeps at timed step 1) must end the job, not hang it: rank 0
+    blocks in the gather, its per-step watchdog thread fires after the deadline and exits 1, the launcher stops the rest.
+    Two ranks on this one GPU over gloo (the control flow of the N > 1 run)."""
+    import os, subprocess, sys, time as _t
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--streams", "4", "--log2-samples", "15", "--chunks", "2", "--backend", "gloo", "--root-streams", "4",
+           "--hang-rank", "1", "--hang-at-step", "1", "--step-deadline-min", "6", "--step-deadline-factor", "1"]
+    t0 = _t.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    took = _t.time() - t0
+    assert r.returncode != 0, "a stuck rank must end the job with a non-zero exit"
+    assert "watchdog" in r.stderr and took < 200, (took, r.stderr[-1500:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no bench line may be printed for a failed job"
 
 
 def test_bench_device_synth_matches_definition():

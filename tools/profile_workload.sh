@@ -9,9 +9,11 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/$tag
 mkdir -p "$out"
-python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.sources_sha())" > "$out/sources_sha.txt" || exit 1
+python3 "$R/tools/sources_sha.py" > "$out/sources_sha.txt" || exit 1
+# the library that will run must have been built from exactly these sources (emspec_build_info)
+python3 -c "import sys; sys.path[:0] = ['$R', '$R/em-spec_amd']; import emspec; i = emspec.build_info(); print(i); sys.exit(0 if ('sources=' + open('$out/sources_sha.txt').read().strip()) in i else 1)" > "$out/build_info.txt" || { echo "libemspec.so is not built from the sources in the tree: rebuild before profiling"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --no-cpu-baseline --steps 5 "$@" > "$out/trace.log" 2>&1 || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$R/bench.py" --no-cpu-baseline --steps 9 --warmup 2 "$@" > "$out/trace.log" 2>&1 || exit 2
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$(echo $c | tr A-Z a-z | sed 's/_size//')
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$d" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$out/pmc_$d.log" 2>&1 || exit 3
