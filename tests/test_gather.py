@@ -8,6 +8,7 @@ import torch
 
 import emspec
 import oracle as O
+from palette import palette_close
 import wire_ref as W
 from emspec import synth
 
@@ -112,8 +113,7 @@ def test_rccl_gather_one_rank_loopback():
             e.gather_columns(idx, root=0, out=packed[:nb], loopback=True, packed=True)
         assert ei.value.code == emspec.ERR_INVALID_ARG
         _, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",))
-        d = np.abs(out[0].cpu().numpy().astype(int) - oidx.astype(int))
-        assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+        palette_close(out[0].cpu().numpy(), oidx)
     with emspec.Engine() as e2:
         with pytest.raises(emspec.EmspecError) as ei:
             e2.gather_columns(torch.zeros((4, 1024), dtype=torch.uint8, device=dev), out=torch.zeros((1, 4, 1024), dtype=torch.uint8, device=dev))

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from palette import palette_close
 from emspec import synth
 
 pytestmark = pytest.mark.gpu
@@ -79,8 +80,7 @@ def test_batch_columns_match_oracle(engine, n, hop, reassign):
     assert out["db"].shape == odb.shape
     # 1e-4 relative on magnitude == 8.7e-4 dB
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
     lut = O.default_lut()
     assert np.array_equal(out["rgba"], lut[out["index"]])
 
@@ -125,8 +125,7 @@ def test_fused_segments_match_oracle(engine, frames, S, reassign, n, hop):
     odb, orgba, oidx = O.batch_f32(cfg, pcm)
     assert out["db"].shape == odb.shape == (S, frames, 1024)
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
 
 
@@ -150,8 +149,7 @@ def test_fused_n16384_matches_oracle(hop, frames, S, reassign, rows):
     odb, orgba, oidx = O.batch_f32(O.make_cfg(n, hop, reassign, rows=rows), pcm)
     assert out["db"].shape == odb.shape == (S, frames, rows)
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
     assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
 
 
@@ -169,8 +167,7 @@ def test_fused_n16384_short_segments(hop, seglen, frames, monkeypatch):
         eng.close()
     odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
 
 
 @pytest.mark.parametrize("n,hop,frames,S", [(4096, 256, 2300, 2), (4096, 512, 700, 3), (8192, 512, 900, 2), (2048, 128, 1500, 2),
@@ -190,8 +187,7 @@ def test_shared_device_segment_plan(n, hop, frames, S, monkeypatch):
         eng.close()
     odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
 
 
 def test_generic_records_path_still_serves_n16384_small_hop(engine):
@@ -223,8 +219,7 @@ def test_fused_other_shapes_short_segments(n, hop, seglen, monkeypatch):
         eng.close()
     odb, _, oidx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 1e-3
+    palette_close(out["index"], oidx)
 
 
 def test_hinted_row_lookup_equals_binary_search(diag_engine):
@@ -338,8 +333,7 @@ def test_other_grids_and_hops(rows, n, hop, reassign):
     odb, _, oidx = O.batch_f32(cfg, pcm, want=("db", "index"))
     assert out["db"].shape == odb.shape == (2, frames, rows)
     assert np.max(np.abs(out["db"] - odb)) < 8.7e-4
-    d = np.abs(out["index"].astype(int) - oidx.astype(int))
-    assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+    palette_close(out["index"], oidx)
     for s in range(2):
         opw, ocol, orow = O.frames_f32(cfg, pcm[s], 0, min(frames, 6))
         assert np.array_equal(col[s], ocol) and np.array_equal(row[s], orow) and np.array_equal(pw[s], opw)
@@ -381,7 +375,7 @@ def test_full_batch_spot_checks_against_oracle(engine):
     torch.cuda.synchronize()
     cfg = O.make_cfg(n, hop, True)
     cols = [0, 1, 7, 8, 9, Cn - 1, Cn - 2, Cn - 9, 1023, 1024, 1025, 511, 512] + list(rng.integers(20, Cn - 20, 12))
-    worst = 0.0
+    worst, bad_cells = 0.0, 0
     for c in cols:
         s = int(rng.integers(0, S))
         f0 = max(0, c - D)
@@ -393,6 +387,9 @@ def test_full_batch_spot_checks_against_oracle(engine):
         worst = max(worst, float(np.max(np.abs(got - ref))))
         d = np.abs(idx[s, c].cpu().numpy().astype(int) - oidx[0, c - f0].astype(int))
         assert d.max() <= 1
+        bad_cells += int(np.count_nonzero(d))
+    print(f"MEASURED palette +-1 cells in the {len(cols)} spot-checked columns: {bad_cells} of {len(cols) * 1024}")
+    assert bad_cells <= max(8, len(cols) * 1024 // 1000)
     assert worst < 8.7e-4, worst
     # identical streams give identical columns (no cross-stream leakage in the batch)
     xb = x.clone()
@@ -524,8 +521,7 @@ def test_display_postprocess(smoothing, agc):
         e.set_display(smoothing, agc)
         out = e.batch(pcm, n, hop, True, want=("db", "index", "rgba"))
         assert np.max(np.abs(out["db"] - want_db)) < 2e-3
-        d = np.abs(out["index"].astype(int) - want_idx.astype(int))
-        assert d.max() <= 1 and np.mean(d != 0) < 2e-3
+        palette_close(out["index"], want_idx)
         assert np.array_equal(out["rgba"], O.default_lut()[out["index"]])
         only_idx = e.batch(pcm[:1], n, hop, True, want=("index",))["index"]       # no dB buffer from the caller
         assert np.array_equal(only_idx, out["index"][:1])
