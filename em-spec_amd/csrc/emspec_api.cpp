@@ -33,7 +33,7 @@ int fail(const emspec_engine* e, int code, const std::string& msg) {
 int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
     if (*have >= want) return EMSPEC_OK;
     if (*ptr) { HIPCHK(e, hipFree(*ptr)); *ptr = nullptr; *have = 0; }
-    HIPCHK(e, hipMalloc(ptr, want));
+    HIPCHK(e, hipMalloc(ptr, want));   // (hipErrorOutOfMemory -> EMSPEC_ERR_OUT_OF_MEMORY; *ptr stays null, *have 0)
     *have = want;
     return EMSPEC_OK;
 }
@@ -176,7 +176,10 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     d.tscale = (float)((double)p.n / 2.0 / (double)hop);
     const double pk = (double)p.n / 4.0;   // |X_h| of a full-scale sine
     d.pfloor_abs = (float)((double)e->cfg.power_floor * pk * pk);
-    d.shared = comm_shares_device(e) ? 1 : 0;
+    // "shared": other kernels take CUs while a fused launch runs - a communicator with other ranks (RCCL transfers, the
+    // gather's pack / expand), or this engine's own two-lane host pipeline (emspec_batch runs neighbouring stream-chunks on
+    // two HIP streams): a one-round plan of very long workgroups then degenerates into two rounds
+    d.shared = (comm_shares_device(e) || e->two_lanes) ? 1 : 0;
     return d;
 }
 
@@ -438,6 +441,27 @@ int emspec_get_tables(emspec_engine* e, int32_t n, float* edges, float* tw) {
 
 }  // extern "C"
 
+// Per-bin record workspaces (the shapes without a fused kernel): streams are processed in chunks so that the workspace
+// stays bounded.  The budget follows the device: a quarter of what is free (counting what this engine already holds),
+// at least 256 MiB, at most `cap` - a chunk only has to cover enough streams to fill the CUs, so a few GiB cost nothing
+// measurable, and a fixed 12 GiB (round 3) pinned that much HBM per EXACT engine for its lifetime.  When the allocation
+// fails all the same, the chunk is halved and tried again; one stream that does not fit is an out-of-memory error.
+static int grow_record_workspace(emspec_engine* e, size_t per_stream, size_t extra, size_t cap, int S, int* chunk_out) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = cap * 4; }
+    size_t budget = (free_b + e->hist_bytes) / 4;
+    budget = budget < ((size_t)256 << 20) ? ((size_t)256 << 20) : (budget > cap ? cap : budget);
+    int chunk = (int)(budget / per_stream);
+    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
+    for (;;) {
+        const int rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, per_stream * (size_t)chunk + extra);
+        if (rc == EMSPEC_OK) { *chunk_out = chunk; return EMSPEC_OK; }
+        (void)hipGetLastError();
+        if (rc != EMSPEC_ERR_OUT_OF_MEMORY || chunk == 1) return rc;
+        chunk = (chunk + 1) / 2;
+    }
+}
+
 // columns of S device-resident streams -> dB / RGBA / index, no display post-process
 static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, const float* pcm, int32_t S, int64_t L,
                        int32_t n, int32_t hop, int32_t reassign, int64_t C, float* db, uint8_t* rgba, uint8_t* index,
@@ -450,10 +474,8 @@ static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, cons
     // generic path: per-bin records (frames_kernel) -> 32-column LDS tiles (tile_scatter_kernel),
     // in chunks of streams so the record workspace stays bounded
     const size_t rec_per_stream = (size_t)C * (n / 2 + 2) * sizeof(uint2);   // frame stride K+1 (even)
-    const size_t budget = (size_t)6 << 30;
-    int chunk = (int)(budget / rec_per_stream);
-    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
-    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, rec_per_stream * chunk))) return rc;
+    int chunk = 1;
+    if ((rc = grow_record_workspace(e, rec_per_stream, 0, (size_t)4 << 30, S, &chunk))) return rc;
     const size_t col_cells = (size_t)C * e->cfg.rows;
     for (int s0 = 0; s0 < S; s0 += chunk) {
         const int sc = (S - s0 < chunk) ? S - s0 : chunk;
@@ -480,10 +502,8 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     }
     const size_t Kp = (size_t)exact_record_stride(n);
     const size_t q_per_stream = (size_t)C * Kp * sizeof(long long), key_per_stream = (size_t)C * Kp * sizeof(uint32_t);
-    const size_t budget = (size_t)12 << 30;
-    int chunk = (int)(budget / (q_per_stream + key_per_stream));
-    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
-    if ((rc = grow(e, (void**)&e->d_hist, &e->hist_bytes, (q_per_stream + key_per_stream) * chunk + 256))) return rc;
+    int chunk = 1;
+    if ((rc = grow_record_workspace(e, q_per_stream + key_per_stream, 256, (size_t)4 << 30, S, &chunk))) return rc;
     const size_t col_cells = (size_t)C * e->cfg.rows;
     for (int s0 = 0; s0 < S; s0 += chunk) {
         const int sc = (S - s0 < chunk) ? S - s0 : chunk;
@@ -699,6 +719,7 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     const int nbuf = two ? 2 : 1;
     if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, (size_t)nbuf * chunk * per_stream + 1024))) { unpin(); return rc; }
     hipError_t herr = hipSuccess;
+    e->two_lanes = two;
     for (int s0 = 0, ci = 0; s0 < S && rc == EMSPEC_OK && herr == hipSuccess; s0 += chunk, ++ci) {
         const int sc = (S - s0 < chunk) ? S - s0 : chunk;
         hipStream_t st = (two && (ci & 1)) ? e->stream2 : e->stream;
@@ -717,6 +738,7 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     }
     hipError_t s1 = hipStreamSynchronize(e->stream);
     hipError_t s2 = e->stream2 ? hipStreamSynchronize(e->stream2) : hipSuccess;
+    e->two_lanes = false;
     unpin();
     if (rc != EMSPEC_OK) return rc;
     HIPCHK(e, herr);

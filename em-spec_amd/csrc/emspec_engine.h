@@ -29,6 +29,7 @@ struct emspec_engine {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second lane of the host-buffer batch pipeline
+    bool two_lanes = false;          // emspec_batch is running chunks on both lanes: fused launches use the shared-device segment plan
     std::string arch;
     mutable std::string err;
     std::map<int, emspec::Plan> plans;

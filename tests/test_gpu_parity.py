@@ -401,6 +401,44 @@ def test_full_batch_spot_checks_against_oracle(engine):
     assert float(torch.max(torch.abs(db2[5] - db2[9]))) < 2e-4
 
 
+def test_full_batch_n16384_spot_checks_against_oracle(engine):
+    """BASELINE configs[4] at full size (64 streams x 2^22 samples, FFT 16384, hop 512: 522,304 columns, one launch of
+    fused16384_kernel: 256 workgroups of 2,041 columns with the ring parked in registers): random (stream, column) cells,
+    the ends of a stream and both sides of the segment boundaries against the oracle on the slice of audio that can
+    reach them (column c depends on frames c-16 .. c+16)."""
+    import torch
+    n, hop, D = 16384, 512, 16
+    S, L = 64, 1 << 22
+    base = synth.streams(4, L)
+    rng = np.random.default_rng(1616)
+    pcm = np.stack([np.roll(base[s % 4], 2311 * s) * (0.5 + 0.5 * ((s * 3) % 5) / 4) for s in range(S)]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pcm).to(dev)
+    Cn = (L - n) // hop + 1
+    assert Cn == 8161 and engine.fused(n, hop, True)
+    db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, Cn, 1024), dtype=torch.uint8, device=dev)
+    engine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    cfg = O.make_cfg(n, hop, True)
+    seg = -(-Cn // 4)       # 64 streams on 256 CUs: four segments per stream
+    cols = [0, 1, 15, 16, 17, Cn - 1, Cn - 2, Cn - 17] + [k * seg + d for k in (1, 2, 3) for d in (-17, -1, 0, 1, 16)] + \
+        list(rng.integers(40, Cn - 40, 8))
+    worst, bad_cells = 0.0, 0
+    for c in cols:
+        s = int(rng.integers(0, S))
+        f0, f1 = max(0, c - D), min(Cn - 1, c + D)
+        odb, _, oidx = O.batch_f32(cfg, pcm[s, f0 * hop:f1 * hop + n][None], want=("db", "index"), threads=1)
+        worst = max(worst, float(np.max(np.abs(db[s, c].cpu().numpy() - odb[0, c - f0]))))
+        d = np.abs(idx[s, c].cpu().numpy().astype(int) - oidx[0, c - f0].astype(int))
+        assert d.max() <= 1, (s, c)
+        bad_cells += int(np.count_nonzero(d))
+    print(f"MEASURED N=16384 full size: max dB error {worst:.2e}, palette +-1 cells {bad_cells} of {len(cols) * 1024}")
+    assert worst < 8.7e-4, worst
+    assert bad_cells <= max(8, len(cols) * 1024 // 1000)
+    engine.device_status()
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a plain C ABI: build a C program against include/emspec.h + libemspec.so and run it."""
     import os

@@ -6,6 +6,7 @@
 # Afterwards, HERE:  python tools/profile_json.py gpurun_out/<tag>_batch64 <tag> batch64 1047616
 #                    python tools/profile_json.py gpurun_out/<tag>_n16384 <tag> n16384 522304
 #                    python tools/profile_json.py gpurun_out/<tag>_paritydump <tag> paritydump 65296
+#                    python tools/profile_json.py gpurun_out/<tag>_exact64 <tag> exact64 1047616
 #                    cp gpurun_out/<tag>_*.txt profiles/   and commit;
 # then a second call for the bench lines, which quote the counters only while profiles/<tag>_*.json match the kernels:
 #   gpurun -- 'python bench.py > gpurun_out/<tag>_bench_n1.json; python bench.py --gather loopback --no-cpu-baseline
@@ -23,9 +24,12 @@ bash tools/profile_workload.sh ${tag}_n16384 --workload n16384 > gpurun_out/prof
 echo "n16384 profiled"
 bash tools/profile_workload.sh ${tag}_paritydump --workload paritydump --steps 20 > gpurun_out/prof_paritydump.log 2>&1
 echo "paritydump profiled"
+bash tools/profile_workload.sh ${tag}_exact64 --mode exact --no-configs > gpurun_out/prof_exact64.log 2>&1
+echo "exact64 profiled"
 cd "$R"
 timeout -k 10 200 python tools/phase_cycles.py 64 waves > gpurun_out/${tag}_batch64_phase_cycles.txt 2>&1
 timeout -k 10 200 python tools/phase_cycles_n16384.py > gpurun_out/${tag}_n16384_phase_cycles.txt 2>&1 || true
+timeout -k 10 200 python tools/phase_cycles_exact.py 64 waves > gpurun_out/${tag}_exact64_phase_cycles.txt 2>&1 || true
 timeout -k 10 200 python tools/kernel_clock.py > gpurun_out/${tag}_kernel_clock.txt 2>&1 || true
 timeout -k 10 200 python tools/gather_cost.py > gpurun_out/${tag}_gather_cost.txt 2>&1 || true
 timeout -k 10 300 python tools/host_rates.py > gpurun_out/${tag}_host_api_rate.txt 2>&1 || true
