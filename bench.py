@@ -728,7 +728,11 @@ def main():
         # the bound the kernel really sits under, in the same shape as `roofline`: VALU issue in the cycle domain (a wave64
         # vector instruction holds its SIMD's pipe 2 cycles - 4 for binary64 - MI355X_MICROARCH.md), with the LDS pipe beside it
         if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
-            cyc = 4.0 if args.mode == "exact" else 2.0
+            # float32 kernels: 2 cycles per wave64 instruction.  EXACT mode: binary64 fma / add / mul / compare hold the pipe 4 cycles,
+            # the rest (integer, float32, conversions, selects) 2; the ISA of exact_fused4096_kernel's frame loop is 48 % binary64
+            # (688 of 1,434 vector instructions, `make asm`), so the mix costs ~2.96 cycles; both extremes are given as well.
+            f64_share = 0.48 if args.mode == "exact" else 0.0
+            cyc = 2.0 + 2.0 * f64_share
             rate = prof["valu_insts_per_column"] * (S * C) / (k_avg_ms * 1e-3)
             peak = SIMDS * prof["clock_ghz"] * 1e9
             sq = prof.get("sq") or {}
@@ -736,13 +740,14 @@ def main():
                         if prof.get("rocprof_median_ms") else None)
             line["roofline_valu"] = {
                 "bound": "valu-issue", "achieved": rate * cyc / 1e9, "peak": peak / 1e9, "unit": "G SIMD-cycles/s",
-                "frac": rate * cyc / peak, "cycles_per_wave_instruction": cyc,
+                "frac": rate * cyc / peak, "cycles_per_wave_instruction": cyc, "binary64_share_of_vector_instructions": f64_share,
+                "frac_if_all_2_cycle": rate * 2.0 / peak, "frac_if_all_4_cycle": (rate * 4.0 / peak) if f64_share else None,
                 "valu_wave_insts_per_column": prof["valu_insts_per_column"], "clock_ghz": prof["clock_ghz"],
                 "lds_pipe_busy_frac": lds_busy, "lds_bank_conflict_share": prof.get("lds_bank_conflict_share"),
                 "wait_any_share": prof.get("wait_any_share"),
                 "note": "live wave-instruction rate (committed SQ_INSTS_VALU per column x this run's columns/s) x cycles per instruction / "
-                        "(1024 SIMDs x the profiled clock); lds_pipe_busy_frac = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles) of the profiled "
-                        "launch (binary64 kernels: the 4-cycle figure is the fma/add/mul rate, so frac is a lower bound of pipe time)",
+                        "(1024 SIMDs x the profiled clock); lds_pipe_busy_frac = SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles) of the "
+                        "profiled launch",
                 "source": prof["file"]}
         else:
             line["roofline_valu"] = None
