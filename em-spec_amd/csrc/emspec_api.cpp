@@ -13,6 +13,7 @@
 #endif
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -451,6 +452,9 @@ static int grow_record_workspace(emspec_engine* e, size_t per_stream, size_t ext
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = cap * 4; }
     size_t budget = (free_b + e->hist_bytes) / 4;
     budget = budget < ((size_t)256 << 20) ? ((size_t)256 << 20) : (budget > cap ? cap : budget);
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_RECORD_BUDGET_MB")) budget = (size_t)atol(ev) << 20;   // test hook: force several stream-chunks
+#endif
     int chunk = (int)(budget / per_stream);
     chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
     for (;;) {

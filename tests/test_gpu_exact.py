@@ -382,3 +382,17 @@ def test_exact_full_size_spot_checks_against_bit_model(xengine):
     xengine.batch_device(x, n, hop, True, db=db, index=idx)
     torch.cuda.synchronize()
     assert chk == (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))
+
+
+@pytest.mark.parametrize("n,hop,S,frames", [(16384, 512, 5, 70), (8192, 512, 4, 90), (4096, 128, 3, 120)])
+def test_exact_record_path_stream_chunks(n, hop, S, frames, monkeypatch):
+    """The shapes that still run as two kernels with per-bin records in HBM (N != 4096, or N = 4096 at a hop whose u64 ring does
+    not fit in LDS) process their streams in chunks so that the record workspace stays bounded; with a forced 64 MB budget the
+    batch below takes several chunks (one or two streams each) - bytes equal to the bit model across the chunk boundaries."""
+    monkeypatch.setenv("EMSPEC_RECORD_BUDGET_MB", "64")
+    pcm = _pcm(n, hop, frames, S=S, extra=3)
+    with emspec.Engine(mode=emspec.MODE_EXACT, diag=True) as e:
+        assert not e.fused(n, hop, True)
+        out = e.batch(pcm, n, hop, True, want=("db", "index"))
+    odb, _, oidx, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.array_equal(out["index"], oidx) and np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
