@@ -61,8 +61,15 @@ function checkExactAgainstJsOracle(fftSize, hop, frames) {
     if (want[i] > -60) { strong++; worst = Math.max(worst, Math.abs(batch[i] - want[i])); }
   }
   if (!(strong > 100 && worst < 8.7e-4)) throw new Error('exact mode vs plain-JS float64 oracle: ' + strong + ' strong cells, worst ' + worst + ' dB');
+  eng.deviceStatus();      // ABI 2: synchronise and throw if a kernel flagged a protocol error (the fused kernels' bounded waits)
   eng.destroy();
   return worst;
+}
+
+/* ABI 2: what the loaded libemspec was built from */
+function checkBuildInfo() {
+  const info = em.buildInfo();
+  if (!/^emspec abi=2 sources=[0-9a-f]{16} arch=gfx950$/.test(info)) throw new Error('unexpected build info: ' + info);
 }
 
 /* multi-GPU entry points on one rank: communicator creation, batch + RCCL gather (world 1: the root's own columns) */
@@ -204,6 +211,7 @@ checkAgainstJsOracle(1024, 256, false, 40);
 checkAgainstJsOracle(4096, 256, true, 48);
 const wx = checkExactAgainstJsOracle(4096, 256, 48);
 checkGatherOneRank();
+checkBuildInfo();
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);
 checkPush(4096, 256, true, 150);
