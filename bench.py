@@ -303,7 +303,7 @@ def main():
                          "the default keeps the lossless packed images on the root (EMSPEC_GATHER_PACKED: directory + images, expanded on "
                          "demand with emspec_wire_unpack) and reports the expanding form beside it")
     ap.add_argument("--step-deadline-factor", type=float, default=20.0,
-                    help="watchdog: a timed step may take this many times the slowest warm-up step (at least --step-deadline-min) before the rank exits 1")
+                    help="watchdog: a run may take max(--step-deadline-min, this x the slowest warm-up step) + 3 x steps x that step before the rank exits 1")
     ap.add_argument("--step-deadline-min", type=float, default=30.0, help="watchdog: the shortest per-step deadline, seconds")
     ap.add_argument("--hang-rank", type=int, default=-1, help="TEST HOOK: this rank stops (sleeps) at --hang-at-step of the timed run")
     ap.add_argument("--hang-at-step", type=int, default=1)
@@ -518,21 +518,17 @@ def main():
 
         def run(self, steps, timed=False, deadline_s=None):
             """barrier, `steps` steps (and the gathers they owe), barrier; returns the elapsed seconds, max over ranks.
-            deadline_s: the watchdog ends this rank when one step (or the closing barrier) takes longer."""
+            deadline_s: the watchdog ends this rank when the whole run - launches are asynchronous, so the host only meets the
+            device again in the closing barrier - takes longer than deadline_s + 3 x steps x the slowest warm-up step."""
             self.wire_bytes[:] = [0, 0]
             if deadline_s:
-                dog.arm(deadline_s, "the opening barrier")
+                dog.arm(deadline_s + 3.0 * steps * max(warm_step_s[0], 0.01), f"a run of {steps} steps")
             barrier()
             t0 = time.perf_counter()
             for i in range(steps):
-                if deadline_s:
-                    dog.arm(deadline_s, f"step {i}")
                 if timed and rank == args.hang_rank and i == args.hang_at_step:     # test hook: a rank that stops making progress
-                    dog.disarm()
                     time.sleep(3600)
                 self.step(timed)
-            if deadline_s:
-                dog.arm(deadline_s, "the last gather + closing barrier")
             self.flush()
             barrier()
             dog.disarm()
@@ -544,6 +540,7 @@ def main():
             return el
 
     dog = Watchdog(rank)
+    warm_step_s = [0.0]               # the slowest warm-up step, seconds (set below; Job.run scales its deadline with it)
     if dist_on and gather_mode == "torch":
         # open the point-to-point connections the gather uses before anything is timed
         probe = torch.zeros(16, dtype=torch.uint8, device=gdev)
@@ -561,7 +558,7 @@ def main():
         split_trials = []
         t_trials = time.perf_counter()
         warm = Job(counts)             # connections, code objects and the allocator's pools: paid before any split is timed
-        warm.run(2)
+        warm.run(2, deadline_s=300.0)   # (connections open here: generous, but a peer that never joins must not hang the job)
         del warm
         # heaviest root first (equal shards), lightest last: if the budget runs out, what was measured includes the default
         for other in sorted({S, S + S // 32, S + S // 16, S + 3 * S // 32, S + S // 8}):
@@ -576,8 +573,8 @@ def main():
                 break
             trial = shard.root_light_counts(world, total_streams, 0, root_count)
             job = Job(trial)
-            job.run(1)                                     # the first gather of a run opens RCCL's connections
-            el = job.run(3)
+            job.run(1, deadline_s=120.0)                   # the first gather of a run opens RCCL's connections
+            el = job.run(3, deadline_s=120.0)
             split_trials.append({"streams_per_rank": trial, "columns_per_s": total_streams * C * 3 / el})
             del job
         measured = [t for t in split_trials if t.get("columns_per_s")]
@@ -598,6 +595,7 @@ def main():
         warm_s = max(warm_s, time.perf_counter() - t0w)
     job.flush()
     dog.disarm()
+    warm_step_s[0] = warm_s
     step_deadline = max(args.step_deadline_min, args.step_deadline_factor * warm_s)
     elapsed = job.run(args.steps, timed=True, deadline_s=step_deadline)
     eng.device_status()           # raises if a kernel flagged a protocol error during the timed run (its columns would be invalid)
