@@ -23,6 +23,12 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#ifdef EMSPEC_DIAG
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#endif
 #include <string>
 #include <vector>
 
@@ -37,8 +43,42 @@ hipError_t launch_wire_unpack(const uint8_t* wire, int64_t columns, int rows, ui
 int64_t wire_fixed_bytes(int64_t columns, int rows);
 }  // namespace emspec
 
+#ifdef EMSPEC_DIAG
+// Diagnostic build only (libemspec_diag.so, EMSPEC_COMM_MOCK=1): an in-process stand-in for the RCCL communicator, so that
+// everything AROUND the three RCCL calls of a gather - the per-rank packing, the (bytes, columns) exchange with its error
+// marks, the root's layout of uneven shards, the directory of the packed form, the expand of several images, the timeout -
+// runs with 2 .. 8 "ranks" (threads, one engine each) on ONE GPU.  One GPU per box is all the tests get, and two ranks on
+// one device are refused by RCCL itself, so before round 4 none of that logic had ever run with world > 1.
+// The stand-in: a generation barrier among the ranks' threads, the size pairs through host memory, and "send/recv" as
+// device-to-device copies enqueued by the root (the ranks share the device's address space).
+struct MockGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, arrived = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    std::vector<uint64_t> pairs;           // [world][2] (image bytes or the error mark, columns)
+    std::vector<const uint8_t*> wire;      // [world] the ranks' packed images (device pointers)
+    bool barrier(double timeout_s) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const uint64_t g = gen;
+        if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); return true; }
+        const auto limit = std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 1e9);
+        const bool ok = cv.wait_for(lk, limit, [&] { return gen != g || broken; });
+        if (!ok || broken) { broken = true; cv.notify_all(); return false; }   // a peer is missing: the group is dead (cf. ncclCommAbort)
+        return true;
+    }
+};
+static std::mutex g_mock_mu;
+static std::map<std::string, std::shared_ptr<MockGroup>> g_mock_groups;
+#endif
+
 struct emspec_comm_state {
     ncclComm_t comm = nullptr;
+#ifdef EMSPEC_DIAG
+    std::shared_ptr<MockGroup> mock;                        // set instead of comm under EMSPEC_COMM_MOCK=1
+#endif
     int rank = 0, world = 1;
     // device workspaces, grown on demand
     uint8_t* d_wire = nullptr; size_t wire_bytes = 0;        // this rank's packed image
@@ -71,6 +111,19 @@ void abort_comm(emspec_comm_state* c) {
         (void)ncclCommAbort(c->comm);
         c->comm = nullptr;
     }
+#ifdef EMSPEC_DIAG
+    if (c && c->mock) {
+        { std::lock_guard<std::mutex> g(c->mock->mu); c->mock->broken = true; }
+        c->mock->cv.notify_all();
+        c->mock.reset();
+    }
+#endif
+}
+bool has_comm(const emspec_comm_state* c) {
+#ifdef EMSPEC_DIAG
+    if (c && c->mock) return true;
+#endif
+    return c && c->comm;
 }
 #define NCCLCHK_ABORT(e, c, call)                                                             \
     do {                                                                                      \
@@ -100,7 +153,7 @@ emspec_comm_state* state(emspec_engine* e) {
 }  // namespace
 
 namespace emspec {
-bool comm_shares_device(const emspec_engine* e) { return e->comm && e->comm->comm && e->comm->world > 1; }
+bool comm_shares_device(const emspec_engine* e) { return has_comm(e->comm) && e->comm->world > 1; }
 void comm_destroy(emspec_engine* e) {
     emspec_comm_state* c = e->comm;
     if (!c) return;
@@ -129,11 +182,24 @@ int emspec_comm_init(emspec_engine* e, const uint8_t* id_bytes, int32_t rank, in
     if (world < 1 || rank < 0 || rank >= world) return fail(e, EMSPEC_ERR_INVALID_ARG, "rank must be in [0, world)");
     emspec_comm_state* c = state(e);
     if (!c) return fail(e, EMSPEC_ERR_OUT_OF_MEMORY, "out of host memory");
-    if (c->comm) return fail(e, EMSPEC_ERR_STATE, "this engine already has a communicator");
+    if (has_comm(c)) return fail(e, EMSPEC_ERR_STATE, "this engine already has a communicator");
     HIPCHK(e, hipSetDevice(e->device));
-    ncclUniqueId id;
-    std::memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
-    NCCLCHK(e, ncclCommInitRank(&c->comm, world, id, rank));
+    bool mocked = false;
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_COMM_MOCK")) mocked = ev[0] == '1';
+    if (mocked) {   // join (or create) the in-process group of this id
+        std::lock_guard<std::mutex> g(g_mock_mu);
+        auto& grp = g_mock_groups[std::string(reinterpret_cast<const char*>(id_bytes), NCCL_UNIQUE_ID_BYTES)];
+        if (!grp) { grp = std::make_shared<MockGroup>(); grp->world = world; grp->pairs.assign(2 * (size_t)world, 0); grp->wire.assign((size_t)world, nullptr); }
+        if (grp->world != world) return fail(e, EMSPEC_ERR_INVALID_ARG, "mock communicator: the ranks disagree about the world size");
+        c->mock = grp;
+    }
+#endif
+    if (!mocked) {
+        ncclUniqueId id;
+        std::memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+        NCCLCHK(e, ncclCommInitRank(&c->comm, world, id, rank));
+    }
     c->rank = rank;
     c->world = world;
     HIPCHK(e, hipMalloc(&c->d_sizes, sizeof(uint64_t) * 2 * (size_t)(world + 1)));
@@ -157,8 +223,8 @@ int emspec_comm_set_timeout(emspec_engine* e, double seconds) {
     return EMSPEC_OK;
 }
 
-int32_t emspec_comm_rank(const emspec_engine* e) { return e && e->comm && e->comm->comm ? e->comm->rank : -1; }
-int32_t emspec_comm_world(const emspec_engine* e) { return e && e->comm && e->comm->comm ? e->comm->world : 0; }
+int32_t emspec_comm_rank(const emspec_engine* e) { return e && has_comm(e->comm) ? e->comm->rank : -1; }
+int32_t emspec_comm_world(const emspec_engine* e) { return e && has_comm(e->comm) ? e->comm->world : 0; }
 
 int64_t emspec_wire_bound(int64_t columns, int32_t rows) {
     if (columns < 0 || rows < 4 || rows % 4) return -1;
@@ -211,7 +277,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
                           int64_t gathered_capacity, uint32_t flags, void* hip_stream, int64_t* wire_bytes_sent) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
     emspec_comm_state* c = e->comm;
-    if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first (or it was aborted after an error)");
+    if (!has_comm(c)) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first (or it was aborted after an error)");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)hip_stream;
     const int R = e->cfg.rows, world = c->world, me = c->rank;
@@ -260,6 +326,22 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     }
     // ---- everybody learns everybody's image size and column count (RCCL counts must match on both sides of a
     // send/recv; shards may differ in size: a host that gives the root fewer streams balances its extra expand work)
+#ifdef EMSPEC_DIAG
+    if (c->mock) {   // in-process stand-in: this rank's pair to the host, then through the group
+        uint64_t mine[2];
+        HIPCHK(e, hipMemcpyAsync(mine, d_total, sizeof(mine), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+        auto grp = c->mock;
+        { std::lock_guard<std::mutex> g(grp->mu); grp->pairs[2 * me] = mine[0]; grp->pairs[2 * me + 1] = mine[1]; grp->wire[me] = c->d_wire; }
+        if (!grp->barrier(c->timeout_s)) {
+            abort_comm(c);
+            return fail(e, EMSPEC_ERR_COMM, "the size exchange of the gather did not complete within the communicator's timeout "
+                                            "(a peer rank is missing); communicator aborted");
+        }
+        { std::lock_guard<std::mutex> g(grp->mu); for (int r = 0; r < 2 * world; ++r) c->h_sizes[r] = grp->pairs[r]; }
+    } else
+#endif
+    {
     NCCLCHK_ABORT(e, c, ncclAllGather(d_total, c->d_sizes, 2, ncclUint64, c->comm, st));
     HIPCHK(e, hipMemcpyAsync(c->h_sizes, c->d_sizes, sizeof(uint64_t) * 2 * (size_t)world, hipMemcpyDeviceToHost, st));
     {   // the one host wait of the call, bounded: a peer that never enters the collective must not hang this rank for ever
@@ -274,6 +356,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
             std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
         HIPCHK(e, q);
+    }
     }
     if (local_rc != EMSPEC_OK) return fail(e, local_rc, local_msg);          // (the peers return EMSPEC_ERR_COMM below)
     for (int r = 0; r < world; ++r)
@@ -306,6 +389,28 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
         if (fits) recv_base = gathered_dev + dir_bytes;            // the images land where they stay
         else if ((rc = grow(e, (void**)&c->d_recv, &c->recv_bytes, off[world] + 256))) return rc; else recv_base = c->d_recv;
     }
+#ifdef EMSPEC_DIAG
+    if (c->mock) {   // "send/recv": the root copies every sender's image device-to-device, then everybody meets again
+        auto grp = c->mock;
+        hipError_t he = hipSuccess;
+        if (is_root) {
+            for (int r = 0; r < world && he == hipSuccess; ++r)
+                if (c->h_sizes[2 * r] > 0 && (r != me || loopback)) {
+                    const uint8_t* src;
+                    { std::lock_guard<std::mutex> g(grp->mu); src = grp->wire[r]; }
+                    he = hipMemcpyAsync(recv_base + off[r], src, (size_t)c->h_sizes[2 * r], hipMemcpyDeviceToDevice, st);
+                }
+            if (he == hipSuccess) he = hipStreamSynchronize(st);      // the senders may reuse their images after the barrier below
+        }
+        const bool met = grp->barrier(c->timeout_s);
+        if (he != hipSuccess || !met) {
+            abort_comm(c);
+            return fail(e, EMSPEC_ERR_COMM, he != hipSuccess ? std::string("mock transfer: ") + hipGetErrorString(he)
+                                                             : std::string("a peer rank left the gather; communicator aborted"));
+        }
+    } else
+#endif
+    {
     NCCLCHK_ABORT(e, c, ncclGroupStart());
     ncclResult_t nr = ncclSuccess;
     if (i_send && c->h_sizes[2 * me] > 0) nr = ncclSend(c->d_wire, (size_t)c->h_sizes[2 * me], ncclUint8, root, c->comm, st);
@@ -317,6 +422,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
     if (nr != ncclSuccess || ge != ncclSuccess) {
         abort_comm(c);
         return fail(e, EMSPEC_ERR_COMM, std::string("ncclSend/ncclRecv: ") + ncclGetErrorString(nr != ncclSuccess ? nr : ge) + " (communicator aborted)");
+    }
     }
 
     if (!fits) return fail(e, EMSPEC_ERR_INVALID_ARG, "the gathered buffer is smaller than the shards the ranks announced");
@@ -354,7 +460,7 @@ int emspec_gather_columns(emspec_engine* e, const uint8_t* index_dev, int64_t co
 }
 
 int emspec_gather_packed_layout(const emspec_engine* e, int32_t rank, int64_t* offset, int64_t* bytes, int64_t* columns) {
-    if (!e || !e->comm || !e->comm->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator");
+    if (!e || !has_comm(e->comm)) return fail(e, EMSPEC_ERR_STATE, "no communicator");
     const emspec_comm_state* c = e->comm;
     if (rank < 0 || rank >= c->world || c->packed_layout.size() != (size_t)c->world * 3)
         return fail(e, EMSPEC_ERR_STATE, "no EMSPEC_GATHER_PACKED gather has completed on this engine as the root");
@@ -368,7 +474,7 @@ int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L
                         int32_t root, uint8_t* gathered_index, float* db_local, int64_t* wire_bytes_sent) {
     if (!e || !pcm) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
     emspec_comm_state* c = e->comm;
-    if (!c || !c->comm) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first");
+    if (!has_comm(c)) return fail(e, EMSPEC_ERR_STATE, "no communicator: call emspec_comm_init first");
     if (root < 0 || root >= c->world) return fail(e, EMSPEC_ERR_INVALID_ARG, "root out of range");
     if (c->rank == root && !gathered_index) return fail(e, EMSPEC_ERR_INVALID_ARG, "the root needs the gathered buffer");
     const int64_t C = emspec_num_columns(L, n, hop);

@@ -2,6 +2,8 @@
 oracle/wire_ref.py, byte for byte) and the RCCL path itself on one rank (communicator creation, size all-gather,
 self send/recv, root-side expand).  More ranks need more GPUs than a box has; the N > 1 control flow is covered with
 gloo on the CPU in tests/test_distributed.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -151,3 +153,162 @@ def test_gather_failure_before_the_exchange_is_collective(monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(out[0], idx)
         assert e.comm_world == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world > 1 on ONE GPU.  RCCL refuses two ranks on one device and a box has one GPU, so until round 4 the library's
+# multi-rank logic - uneven shards laid out in rank order on the root, the directory of the packed form, several images
+# expanded, the error mark travelling through the size exchange, the timeout - had only ever run with world = 1.  The
+# diagnostic build has an in-process stand-in for the three RCCL calls (EMSPEC_COMM_MOCK=1, emspec_comm.cpp: a barrier
+# among the ranks' threads, the size pairs through host memory, send/recv as device-to-device copies); everything else
+# is the product code.  One thread per rank, one engine each.
+
+def _run_ranks(world, fn):
+    import threading
+    errs, res = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            res[r] = fn(r)
+        except BaseException as ex:     # noqa: BLE001 - reported to the main thread
+            errs[r] = ex
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank thread is stuck in the collective"
+    return res, errs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,packed", [(2, False), (4, False), (4, True), (8, True), (8, False)])
+def test_gather_many_ranks_on_one_gpu(world, packed, monkeypatch):
+    """Uneven shards (1-4 streams per rank), gathered to rank 0: expanding form == the ranks' own columns one after the other in
+    rank order; packed form: directory + images, every image expands to its rank's columns."""
+    monkeypatch.setenv("EMSPEC_COMM_MOCK", "1")
+    n, hop, frames = 4096, 256, 48
+    counts = [3, 1, 2, 4, 2, 1, 3, 2][:world]
+    L = n + hop * (frames - 1)
+    pcm_all = synth.streams(sum(counts), L)
+    cid = emspec.comm_unique_id()
+    dev = torch.device("cuda", 0)
+    rows = 1024
+    total_cols = sum(counts) * frames
+
+    def rank(r):
+        first, S = sum(counts[:r]), counts[r]
+        with emspec.Engine(diag=True) as e:
+            e.comm_set_timeout(60.0)
+            e.comm_init(cid, r, world)
+            assert (e.comm_rank, e.comm_world) == (r, world)
+            st = torch.cuda.Stream(device=dev)
+            x = torch.from_numpy(pcm_all[first:first + S]).to(dev)
+            idx = torch.empty((S, frames, rows), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            e.batch_device(x, n, hop, True, index=idx, stream=st)
+            out = None
+            if r == 0:
+                cap = (256 * (world + 1) + sum(emspec.wire_bound(c * frames, rows) for c in counts)) if packed else total_cols * rows
+                out = torch.full((cap,), 0xA5, dtype=torch.uint8, device=dev)
+            sent = e.gather_columns(idx, root=0, out=out, stream=st, packed=packed)
+            st.synchronize()
+            got = None
+            if r == 0 and not packed:
+                got = out.view(total_cols, rows).cpu().numpy()
+            if r == 0 and packed:
+                blocks = []
+                for q in range(world):
+                    off, nb, cols = e.gather_packed_layout(q)
+                    assert cols == counts[q] * frames and off % 256 == 0 and nb > 32
+                    back = torch.empty((cols, rows), dtype=torch.uint8, device=dev)
+                    e.wire_unpack(out[off:], nb, back, stream=st)
+                    st.synchronize()
+                    blocks.append(back.cpu().numpy())
+                got = np.concatenate(blocks)
+            return idx.cpu().numpy().reshape(-1, rows), got, sent
+
+    res, errs = _run_ranks(world, rank)
+    assert not any(errs), errs
+    want = np.concatenate([res[r][0] for r in range(world)])
+    assert np.array_equal(res[0][1], want)
+    assert all(res[r][2] > 32 for r in range(1, world)) and (res[0][2] == 0 or packed)
+
+
+@pytest.mark.gpu
+def test_gather_failure_on_one_of_four_ranks_ends_the_call_everywhere(monkeypatch):
+    """world = 4, rank 2 fails before the size exchange (injected): rank 2 returns its own error, ranks 0, 1, 3 return
+    EMSPEC_ERR_COMM from the SAME call - nobody is left in the collective - nothing is written on the root, and the next
+    gather of the same communicator works."""
+    monkeypatch.setenv("EMSPEC_COMM_MOCK", "1")
+    world, n, hop, frames, rows = 4, 4096, 256, 24, 1024
+    pcm_all = synth.streams(world, n + hop * (frames - 1))
+    cid = emspec.comm_unique_id()
+    dev = torch.device("cuda", 0)
+    import threading
+    gate = threading.Barrier(world)
+
+    def rank(r):
+        with emspec.Engine(diag=True) as e:
+            e.comm_set_timeout(60.0)
+            e.comm_init(cid, r, world)
+            st = torch.cuda.Stream(device=dev)
+            idx = torch.empty((1, frames, rows), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            e.batch_device(torch.from_numpy(pcm_all[r:r + 1]).to(dev), n, hop, True, index=idx, stream=st)
+            out = torch.full((world * frames * rows,), 0x3C, dtype=torch.uint8, device=dev) if r == 0 else None
+            gate.wait()
+            if r == 0:
+                os.environ["EMSPEC_GATHER_FAIL_RANK"] = "2"
+            gate.wait()
+            code = 0
+            try:
+                e.gather_columns(idx, root=0, out=out, stream=st)
+            except emspec.EmspecError as ex:
+                code = ex.code
+            gate.wait()
+            if r == 0:
+                os.environ.pop("EMSPEC_GATHER_FAIL_RANK")
+                st.synchronize()
+                assert bool((out == 0x3C).all())
+            gate.wait()
+            e.gather_columns(idx, root=0, out=out, stream=st)      # the communicator survived
+            st.synchronize()
+            return code, (out.view(world, frames, rows).cpu().numpy() if r == 0 else idx.cpu().numpy())
+
+    res, errs = _run_ranks(world, rank)
+    assert not any(errs), errs
+    assert [c for c, _ in res] == [emspec.ERR_COMM, emspec.ERR_COMM, emspec.ERR_OOM, emspec.ERR_COMM]
+    assert np.array_equal(res[0][1], np.concatenate([res[r][1] if r else res[0][1][0:1] for r in range(world)]))
+
+
+@pytest.mark.gpu
+def test_gather_missing_rank_times_out(monkeypatch):
+    """world = 3 but rank 2 never calls the gather: ranks 0 and 1 return EMSPEC_ERR_COMM when the communicator's timeout
+    expires (2 s here) instead of waiting for ever, and the communicator is gone afterwards (EMSPEC_ERR_STATE)."""
+    monkeypatch.setenv("EMSPEC_COMM_MOCK", "1")
+    world, rows = 3, 1024
+    cid = emspec.comm_unique_id()
+    dev = torch.device("cuda", 0)
+    import time
+
+    def rank(r):
+        with emspec.Engine(diag=True) as e:
+            e.comm_set_timeout(2.0)
+            e.comm_init(cid, r, world)
+            if r == 2:
+                return None
+            idx = torch.zeros((4, rows), dtype=torch.uint8, device=dev)
+            out = torch.zeros((world * 4 * rows,), dtype=torch.uint8, device=dev) if r == 0 else None
+            t0 = time.time()
+            with pytest.raises(emspec.EmspecError) as ei:
+                e.gather_columns(idx, root=0, out=out)
+            assert ei.value.code == emspec.ERR_COMM and "timeout" in str(ei.value)
+            with pytest.raises(emspec.EmspecError) as ei2:
+                e.gather_columns(idx, root=0, out=out)
+            assert ei2.value.code == emspec.ERR_STATE
+            return time.time() - t0
+
+    res, errs = _run_ranks(world, rank)
+    assert not any(errs), errs
+    assert 1.5 < res[0] < 30 and 1.5 < res[1] < 30
