@@ -177,10 +177,12 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     d.tscale = (float)((double)p.n / 2.0 / (double)hop);
     const double pk = (double)p.n / 4.0;   // |X_h| of a full-scale sine
     d.pfloor_abs = (float)((double)e->cfg.power_floor * pk * pk);
-    // "shared": other kernels take CUs while a fused launch runs - a communicator with other ranks (RCCL transfers, the
-    // gather's pack / expand), or this engine's own two-lane host pipeline (emspec_batch runs neighbouring stream-chunks on
-    // two HIP streams): a one-round plan of very long workgroups then degenerates into two rounds
-    d.shared = (comm_shares_device(e) || e->two_lanes) ? 1 : 0;
+    // "shared" = 1: other kernels take CUs while a fused launch runs (a communicator with other ranks: RCCL transfers, the
+    // gather's pack / expand) -> the shared-device segment plan.  2: this engine's own two-lane host pipeline (emspec_batch
+    // runs neighbouring stream-chunks on two HIP streams): two fused launches share the chip, so segments are capped at
+    // 1,024 columns (a one-round plan of very long workgroups would degenerate into two rounds); the chunks of that pipeline
+    // are small (96 MB of staging), so their segments are short anyway and keep the exclusive plan's low halo.
+    d.shared = comm_shares_device(e) ? 1 : (e->two_lanes ? 2 : 0);
     return d;
 }
 

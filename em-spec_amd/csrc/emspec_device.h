@@ -23,7 +23,8 @@ struct PlanDev {
     int hop;
     float tscale;        // (N/2)/hop : normalised time shift -> columns
     float pfloor_abs;    // gate on |X_h|^2
-    int shared;          // host side only: the device is shared with a collective (engine has a communicator, world > 1)
+    int shared;          // host side only: 1 = the device is shared with a collective (communicator, world > 1); 2 = with the
+                         // engine's own second pipeline lane (emspec_batch): segments capped at 1,024 columns
 };
 
 // How a launch of a fused (walking) kernel cuts every stream into segments.
