@@ -73,3 +73,15 @@ def test_host_cores_respects_quota_and_smt():
 def test_roofline_helper():
     r = bench.roofline(1000, 6144, 1.0)
     assert abs(r["achieved"] - 1000 * 6144 / 1e-3 / 1e9) < 1e-9 and r["frac"] == r["achieved"] / 8000.0
+
+
+def test_watchdog_ends_the_process():
+    """bench.Watchdog: a deadline that expires ends the process with exit code 1 (os._exit from the watchdog thread - no re-exec,
+    nothing that needs the main thread, which may be blocked inside a collective); a disarmed one does not."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; d = bench.Watchdog(3); d.arm(%s, 'the test step'); "
+            "time.sleep(%s); d.disarm(); time.sleep(1.2); print('survived')")
+    late = subprocess.run([sys.executable, "-c", code % (ROOT, "0.3", "30")], capture_output=True, text=True, timeout=120)
+    assert late.returncode == 1 and "watchdog" in late.stderr and "the test step" in late.stderr and "survived" not in late.stdout
+    ok = subprocess.run([sys.executable, "-c", code % (ROOT, "20", "0.1")], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and "survived" in ok.stdout
