@@ -14,6 +14,11 @@
 //     pack (GPU)  ->  ncclAllGather of the 8-byte image sizes  ->  one host sync to read them
 //     ->  grouped ncclSend (ranks) / ncclRecv x (world-1) (root)  ->  expand on the root (GPU)
 // all enqueued on the caller's stream.
+// Failure semantics (round 4): what can fail on one rank alone is detected before the size exchange and travels through it
+// as an error mark, so every rank returns from the same call; the one host wait is bounded (emspec_comm_set_timeout); an RCCL
+// error or a missing peer aborts the communicator.  The diagnostic build can replace the three RCCL calls by an in-process
+// stand-in (EMSPEC_COMM_MOCK=1, MockGroup below) so that the multi-rank logic runs with 2 .. 8 ranks on one GPU
+// (tests/test_gather.py).
 #include "emspec_engine.h"
 
 #include <rccl/rccl.h>
