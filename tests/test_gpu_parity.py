@@ -516,10 +516,10 @@ np.savez(sys.argv[1], db=out["db"], index=out["index"])
 """
 
 
-@pytest.mark.parametrize("variant", ["r8", "ppt", "r8t", "r16"])
+@pytest.mark.parametrize("variant", ["r8", "pp3", "ppt", "r8t", "r16"])
 def test_fused_ab_variants_match_the_product(variant, tmp_path):
     """The A/B variants of the N = 4096 kernel kept in libemspec_diag.so (lock step `r8` = the default of rounds 1-2,
-    software team barriers `ppt`, decoupled teams `r8t`, 512-thread radix-16 `r16`) compute the same
+    `pp3` = the product of rounds 3-4 with the spectrum reads at the start of role 1, its software-team-barrier form `ppt`, decoupled teams `r8t`, 512-thread radix-16 `r16`) compute the same
     columns as the product kernel: same arithmetic per bin, only the order of the float32 histogram sums differs, so dB
     agrees to a few ulp and the palette index may differ by one step on a handful of cells.  One child process per
     variant (the switch is read once per process)."""

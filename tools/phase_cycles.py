@@ -31,9 +31,11 @@ assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(),
 torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
-# the product kernel (two teams half an iteration apart, fused_pp.hip.inc) stamps these phases; EMSPEC_FUSED_VARIANT=r8 (the
-# lock-step A/B variant) the second list
-names = ["finalize", "passes B C D", "bins", "scatter", "next pass A", "team wait", "write+barrier", "-"]
+# the product kernel (two teams half an iteration apart, fused_pp.hip.inc) stamps these phases; EMSPEC_FUSED_VARIANT=pp3 / ppt
+# (round 3's form of it) the second list, r8 (the lock-step A/B variant) the third
+names = ["finalize", "passes B C D", "bins", "scatter+next A", "spectrum reads", "team wait", "write+barriers", "-"]
+if os.environ.get("EMSPEC_FUSED_VARIANT", "")[:3] in ("pp3", "ppt"):
+    names = ["finalize", "passes B C D", "bins", "scatter", "next pass A", "team wait", "write+barrier", "-"]
 if os.environ.get("EMSPEC_FUSED_VARIANT", "").startswith("r8") and os.environ.get("EMSPEC_FUSED_VARIANT") != "r8t":
     names = ["passA+write", "barrier wait", "finalize+passB", "passC r/c", "passD in place", "bins", "scatter+next A", "-"]
 tot = cyc[:, :, :7].sum(axis=2).astype(np.float64)    # slot 7 is not a phase: rounds (low word) + 100 MHz ticks (high word)
