@@ -23,6 +23,27 @@ from emspec import synth
 
 pytestmark = pytest.mark.gpu
 
+@pytest.mark.parametrize("n,hop,frames", [(16384, 512, 10), (1024, 256, 48), (8192, 512, 12), (4096, 256, 40)])
+def test_exact_without_power_floor_runs_the_generic_core(n, hop, frames):
+    """power_floor = 0 takes a plan off the branch-free per-bin core (its short reciprocal needs 64 P >= 64e-200): every
+    EXACT kernel then runs its generic core on the log axis - the template instances the usual plans no longer reach since
+    round 4 (exact_frames_kernel<.., false>, exact_frames16384_kernel<false>, exact_fused4096_kernel<.., false, ..>).
+    Dump and finished columns against the bit model, as for the fast plans."""
+    pcm = _pcm(n, hop, frames, S=2)
+    pcm[1, : n // 2] = 0.0                                   # exact zeros: bins with P = 0 pass a zero floor
+    with emspec.Engine(mode=emspec.MODE_EXACT, power_floor=0.0) as e:
+        cfg = O.make_cfg(n, hop, True, power_floor=0.0)
+        pw, col, row, q = e.parity_dump_exact(pcm, n, hop, True, 0, frames)
+        for s_ in range(2):
+            opw, ocol, orow, oq = O.frames_exact(cfg, pcm[s_], 0, frames)
+            assert np.array_equal(row[s_], orow) and np.array_equal(col[s_], ocol) and np.array_equal(q[s_], oq)
+            assert np.array_equal(pw[s_].view(np.uint64), opw.view(np.uint64))
+        out = e.batch(pcm, n, hop, True, want=("db", "index"))
+        odb, _, oidx, _ = O.batch_exact(cfg, pcm, want=("db", "index"))
+        assert np.array_equal(out["index"], oidx)
+        assert np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
+
+
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
 
 
