@@ -310,6 +310,9 @@ def main():
     ap.add_argument("--trial-budget-s", type=float, default=60.0,
                     help="N>1: wall-clock budget of the stream-split trials; when it is spent the remaining splits are skipped "
                          "(none measured: the modelled split, root 8 streams lighter per other rank, is used)")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="TEST HOOK: every rank joins a gloo group, rank 0 prints a one-line JSON with the ranks' pids, nothing "
+                         "touches a GPU (the CPU test of the self-spawning launcher); --hang-rank R makes rank R exit 3")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 control flow on fewer GPUs than ranks (torch gather via host tensors)")
     args = ap.parse_args()
@@ -319,8 +322,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        # (a plain `bench.py --gpus N` never gets here: spawn_ranks() started the N ranks and relayed their line)
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if args.dry_run_ranks:
+        # TEST HOOK: the N > 1 start-up without a GPU - rendezvous, one reduction, rank 0's single line
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        seen = torch.zeros(world, dtype=torch.int64)
+        seen[rank] = os.getpid()
+        dist.all_reduce(seen)
+        if rank == 0:
+            json_out.write(json.dumps({"dry_run": True, "n_gpus": world, "pids": seen.tolist(), "steps": args.steps}) + "\n")
+            json_out.flush()
+        print(f"[bench rank {rank}] dry run: {world} ranks met")          # (stdout is stderr here: must not reach the line)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == args.hang_rank:
+            sys.exit(3)
+        return
     dist = None
     dist_on = world > 1 or args.gather == "dist-loopback"     # torch.distributed initialised (N>1, or the one-rank rehearsal of it)
     if dist_on:
@@ -851,7 +870,72 @@ def main():
     eng.close()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset: the driver's own command form):
+    start the N ranks as a CHILD process - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same arguments>` - relay rank 0's single JSON line to stdout, everything else
+    to stderr, and return the child's exit code.  Returns None when there is nothing to spawn (N = 1, or already a rank of
+    an external launcher).  This parent makes NO GPU call (argument parsing and torch.cuda.device_count() only, which does
+    not initialise HIP on this image) and never execs: the ranks are children (rccl.h:220 ncclCommInitRank runs in them)."""
+    import signal
+    import subprocess
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    pre.add_argument("--backend", default="nccl")
+    pre.add_argument("--dry-run-ranks", action="store_true")
+    known, _ = pre.parse_known_args(argv)
+    if known.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if known.backend == "nccl" and not known.dry_run_ranks:
+        have = torch.cuda.device_count()
+        if have < known.gpus:          # RCCL refuses two ranks on one device: say so in a line the driver can parse
+            print(json.dumps({"error": f"--gpus {known.gpus} with --backend nccl needs {known.gpus} visible GPUs, found {have}",
+                              "n_gpus": known.gpus, "visible_gpus": have, "metric": None, "value": None}), flush=True)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _HOST_CORES[0] // known.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(known.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (known.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+
+    def forward(signum, _frame):       # the driver's timeout must reach the ranks, not only this relay
+        try:
+            child.send_signal(signum)
+        except Exception:
+            pass
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sg, forward)
+    lines = 0
+    for ln in child.stdout:
+        if ln.startswith("{") and lines == 0:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"[bench] the ranks exited 0 but printed {lines} JSON lines\n")
+        rc = 1
+    return rc if rc >= 0 else 128 - rc
+
+
 if __name__ == "__main__":
+    _rc = spawn_ranks(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
     try:
         main()
     except SystemExit:

@@ -121,3 +121,40 @@ def test_two_rank_uneven_gather_matches_single_process(tmp_path):
     pcm = synth.streams(sum(counts), n + hop * (frames - 1))
     _, _, idx = O.batch_f32(O.make_cfg(n, hop, True), pcm, want=("index",), threads=1)
     assert got.shape == idx.shape and np.array_equal(got, idx)
+
+
+def _plain_bench(args, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(300)
+def test_plain_bench_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form) starts the two ranks itself as a
+    child `python -m torch.distributed.run`, relays rank 0's ONE JSON line to stdout (everything else to stderr) and exits
+    with the child's code.  --dry-run-ranks keeps the ranks off the GPU: rendezvous + one reduction over gloo."""
+    import json
+    r = _plain_bench(["--gpus", "2", "--steps", "7", "--backend", "gloo", "--dry-run-ranks"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout                       # nothing but the line on stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 7 and len(set(b["pids"])) == 2 and os.getpid() not in b["pids"]
+    assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
+    # a failing rank's exit code ends the parent non-zero
+    r = _plain_bench(["--gpus", "2", "--backend", "gloo", "--dry-run-ranks", "--hang-rank", "1"])
+    assert r.returncode != 0
+
+
+def test_plain_bench_invocation_refuses_more_ranks_than_gpus():
+    """--gpus N over RCCL needs N devices (RCCL refuses two ranks on one): a JSON error line and a non-zero exit, not a hang."""
+    import json
+    import torch as _t
+    if _t.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the refusal cannot be provoked")
+    r = _plain_bench(["--gpus", "2"], timeout=120)
+    assert r.returncode != 0
+    b = json.loads(r.stdout.splitlines()[0])
+    assert "error" in b and b["n_gpus"] == 2 and b["value"] is None

@@ -772,6 +772,30 @@ def test_bench_two_rank_rehearsal():
     assert b["value"] > 0 and b["cpu_baseline"] is None
 
 
+def test_bench_plain_invocation_starts_two_ranks():
+    """The driver's own command form, `python bench.py --gpus 2 ...` with no launcher around it: bench.py starts its two
+    ranks as a child `python -m torch.distributed.run` (the parent never touches the GPU), relays rank 0's one JSON line and
+    exits 0.  Two ranks on this one GPU over gloo; at N = 8 the same code path runs over RCCL (rccl.h:220)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--streams", "6", "--log2-samples", "18", "--chunks", "3", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]     # ONLY the line reaches stdout
+    b = json.loads(lines[0])
+    C = (2 ** 18 - 4096) // 256 + 1
+    assert b["n_gpus"] == 2 and b["config"]["columns_per_step"] == 2 * 6 * C and b["value"] > 0
+    # over RCCL the same invocation needs two devices: a JSON error line and a non-zero exit on this one-GPU box
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd[:-2], capture_output=True, text=True, timeout=120, env=env, cwd=root)
+        assert r.returncode != 0 and "error" in json.loads(r.stdout.splitlines()[0])
+
+
 def test_bench_two_rank_uneven_split_rehearsal():
     """The N > 1 stream split (the collecting rank takes a lighter shard; bench.py tries five splits and keeps the fastest)
     rehearsed with two ranks on this one GPU over gloo: the trial loop, the re-built buffers and the uneven point-to-point
