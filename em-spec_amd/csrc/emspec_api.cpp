@@ -84,6 +84,63 @@ void cos_sin_octant(double a, double* c, double* s) {
     *c = 1.0 - pc * z;
 }
 
+// (oracle/emspec_oracle.c: eo_spec_pow states the same operations)
+/* ratio^x by a SPECIFIED evaluation: exp2(x * log2(ratio)) from plain IEEE binary64 operations in this
+ * order - no libm, whose pow() is not correctly rounded and differs between C libraries, so a table built from it would
+ * depend on the host.  log2 as in the EXACT mode's dB (exact.hip.inc: exact_db) (atanh series on the mantissa folded into [1/sqrt2, sqrt2]); 2^f, |f| <= 1/2,
+ * by the Taylor series of e^(f ln 2) in Horner form (truncation < 4e-18); scaling by 2^i is exact.  Within ~3 ulp of the
+ * real value; what matters is that every build produces the same bits. */
+static double spec_log2(double x) {
+    uint64_t u;
+    memcpy(&u, &x, 8);
+    int e = (int)((u >> 52) & 0x7ff) - 1023;
+    u = (u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &u, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double pz = 1.0 / 21.0;
+    pz = pz * z + 1.0 / 19.0;
+    pz = pz * z + 1.0 / 17.0;
+    pz = pz * z + 1.0 / 15.0;
+    pz = pz * z + 1.0 / 13.0;
+    pz = pz * z + 1.0 / 11.0;
+    pz = pz * z + 1.0 / 9.0;
+    pz = pz * z + 1.0 / 7.0;
+    pz = pz * z + 1.0 / 5.0;
+    pz = pz * z + 1.0 / 3.0;
+    pz = pz * z + 1.0;
+    return (double)e + (s * pz) * 2.8853900817779268; /* 2 / ln 2 */
+}
+static double spec_exp2(double x) {
+    const double i = (double)(long long)(x < 0.0 ? x - 0.5 : x + 0.5); /* nearest integer (halves away from zero) */
+    const double t = (x - i) * 0.6931471805599453;                    /* x - i is exact; |t| <= 0.3466 */
+    double p = 1.0 / 87178291200.0;      /* 1/14! */
+    p = p * t + 1.0 / 6227020800.0;      /* 1/13! */
+    p = p * t + 1.0 / 479001600.0;       /* 1/12! */
+    p = p * t + 1.0 / 39916800.0;        /* 1/11! */
+    p = p * t + 1.0 / 3628800.0;         /* 1/10! */
+    p = p * t + 1.0 / 362880.0;          /* 1/9! */
+    p = p * t + 1.0 / 40320.0;           /* 1/8! */
+    p = p * t + 1.0 / 5040.0;            /* 1/7! */
+    p = p * t + 1.0 / 720.0;             /* 1/6! */
+    p = p * t + 1.0 / 120.0;             /* 1/5! */
+    p = p * t + 1.0 / 24.0;              /* 1/4! */
+    p = p * t + 1.0 / 6.0;               /* 1/3! */
+    p = p * t + 0.5;                     /* 1/2! */
+    p = p * t + 1.0;
+    p = p * t + 1.0;
+    const uint64_t su = (uint64_t)(1023 + (long long)i) << 52;        /* 2^i, |i| < 1000 */
+    double sd;
+    memcpy(&sd, &su, 8);
+    return p * sd;
+}
+static double spec_pow(double ratio, double x) {
+    if (x == 1.0) return ratio; /* the axis ends exactly at fmax (as pow(ratio, 1) would) */
+    return spec_exp2(x * spec_log2(ratio));
+}
+
 int latency(int n, int hop, int reassign) { return reassign ? (n + 2 * hop - 1) / (2 * hop) : 0; }
 
 int check_shape(const emspec_engine* e, int n, int hop) {
@@ -119,7 +176,7 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
     const double ratio = (double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz;
     for (int r = 0; r <= R; ++r)
         p.h_ebin[r] = e->custom_edges_hz.empty()
-                          ? (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n /
+                          ? (float)((double)e->cfg.fmin_hz * spec_pow(ratio, (double)r / (double)R) * (double)n /
                                     (double)e->cfg.sample_rate)
                           : (float)((double)e->custom_edges_hz[r] * (double)n / (double)e->cfg.sample_rate);
     for (int r = 0; r < R; ++r)
@@ -149,7 +206,7 @@ int get_plan(emspec_engine* e, int n, Plan** out) {
         tw[2 * (n / 4) + 1] = -1.0;
         for (int r = 0; r <= R; ++r)
             eb[r] = e->custom_edges_hz.empty()
-                        ? (double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R) * (double)n / (double)e->cfg.sample_rate
+                        ? (double)e->cfg.fmin_hz * spec_pow(ratio, (double)r / (double)R) * (double)n / (double)e->cfg.sample_rate
                         : (double)e->custom_edges_hz[r] * (double)n / (double)e->cfg.sample_rate;
         for (int r = 0; r < R; ++r)
             if (!(eb[r] < eb[r + 1])) return fail(e, EMSPEC_ERR_INVALID_ARG, "row edges are not strictly increasing");
@@ -398,7 +455,7 @@ int emspec_get_row_edges_hz(emspec_engine* e, float* edges_hz, int32_t count) {
     const int R = e->cfg.rows;
     const double ratio = (double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz;
     for (int r = 0; r <= R; ++r)
-        edges_hz[r] = e->custom_edges_hz.empty() ? (float)((double)e->cfg.fmin_hz * std::pow(ratio, (double)r / (double)R))
+        edges_hz[r] = e->custom_edges_hz.empty() ? (float)((double)e->cfg.fmin_hz * spec_pow(ratio, (double)r / (double)R))
                                                  : e->custom_edges_hz[r];
     return EMSPEC_OK;
 }

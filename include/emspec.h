@@ -85,9 +85,9 @@ typedef struct emspec_config {
  *   EMSPEC_MODE_EXACT  binary64 from the frame to the indices, energy summed in 64-bit fixed point (order-
  *                      independent), dB through a specified binary64 polynomial: (column,row) agree
  *                      with a float64 implementation of the three-window method on every bin, and dB / palette index /
- *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes (one caveat: the
- *                      log-spaced row edges are built with the platform's pow() on both sides - every other table is a
- *                      specified evaluation - so equality ACROSS machines assumes the same libm; "(column,row) agree with a
+ *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes (every table - twiddles,
+ *                      log-spaced row edges, dB polynomial - is a specified sequence of IEEE operations, no libm call, so the
+ *                      bytes do not depend on the host's C library; "(column,row) agree with a
  *                      float64 implementation on every bin" is a measured statement: 0 mismatches in > 10^8 values, where
  *                      two binary64 evaluations may still differ on a bin within ~1e-13 of an edge).  Inputs must stay
  *                      within |x| <= 4 (the fixed point covers 2^11 full-scale-sine powers per cell).  Same entry points;

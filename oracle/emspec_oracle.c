@@ -62,6 +62,61 @@ int eo_set_custom_edges_hz(const float* hz, int count) {
     return 0;
 }
 
+
+/* ratio^x by a SPECIFIED evaluation: exp2(x * log2(ratio)) from plain IEEE binary64 operations in this
+ * order - no libm, whose pow() is not correctly rounded and differs between C libraries, so a table built from it would
+ * depend on the host.  log2 as in eo_exact_db (atanh series on the mantissa folded into [1/sqrt2, sqrt2]); 2^f, |f| <= 1/2,
+ * by the Taylor series of e^(f ln 2) in Horner form (truncation < 4e-18); scaling by 2^i is exact.  Within ~3 ulp of the
+ * real value; what matters is that every build produces the same bits. */
+static double spec_log2(double x) {
+    union { double d; uint64_t u; } v;
+    v.d = x;
+    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = v.d;
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double pz = 1.0 / 21.0;
+    pz = pz * z + 1.0 / 19.0;
+    pz = pz * z + 1.0 / 17.0;
+    pz = pz * z + 1.0 / 15.0;
+    pz = pz * z + 1.0 / 13.0;
+    pz = pz * z + 1.0 / 11.0;
+    pz = pz * z + 1.0 / 9.0;
+    pz = pz * z + 1.0 / 7.0;
+    pz = pz * z + 1.0 / 5.0;
+    pz = pz * z + 1.0 / 3.0;
+    pz = pz * z + 1.0;
+    return (double)e + (s * pz) * 2.8853900817779268; /* 2 / ln 2 */
+}
+static double spec_exp2(double x) {
+    const double i = (double)(long long)(x < 0.0 ? x - 0.5 : x + 0.5); /* nearest integer (halves away from zero) */
+    const double t = (x - i) * 0.6931471805599453;                    /* x - i is exact; |t| <= 0.3466 */
+    double p = 1.0 / 87178291200.0;      /* 1/14! */
+    p = p * t + 1.0 / 6227020800.0;      /* 1/13! */
+    p = p * t + 1.0 / 479001600.0;       /* 1/12! */
+    p = p * t + 1.0 / 39916800.0;        /* 1/11! */
+    p = p * t + 1.0 / 3628800.0;         /* 1/10! */
+    p = p * t + 1.0 / 362880.0;          /* 1/9! */
+    p = p * t + 1.0 / 40320.0;           /* 1/8! */
+    p = p * t + 1.0 / 5040.0;            /* 1/7! */
+    p = p * t + 1.0 / 720.0;             /* 1/6! */
+    p = p * t + 1.0 / 120.0;             /* 1/5! */
+    p = p * t + 1.0 / 24.0;              /* 1/4! */
+    p = p * t + 1.0 / 6.0;               /* 1/3! */
+    p = p * t + 0.5;                     /* 1/2! */
+    p = p * t + 1.0;
+    p = p * t + 1.0;
+    union { double d; uint64_t u; } s;
+    s.u = (uint64_t)(1023 + (long long)i) << 52;                      /* 2^i, |i| < 1000 */
+    return p * s.d;
+}
+double eo_spec_pow(double ratio, double x) {
+    if (x == 1.0) return ratio; /* the axis ends exactly at fmax (as pow(ratio, 1) would) */
+    return spec_exp2(x * spec_log2(ratio));
+}
+
 static void make_edges64(const eo_cfg* c, double* e) {
     /* row edges expressed in DFT-bin units (Hz * N / fs): custom table, or log-spaced */
     if (g_custom_edges && g_custom_count == c->rows + 1) {
@@ -70,7 +125,7 @@ static void make_edges64(const eo_cfg* c, double* e) {
     }
     double ratio = (double)c->fmax_hz / (double)c->fmin_hz;
     for (int r = 0; r <= c->rows; ++r)
-        e[r] = (double)c->fmin_hz * pow(ratio, (double)r / (double)c->rows) *
+        e[r] = (double)c->fmin_hz * eo_spec_pow(ratio, (double)r / (double)c->rows) *
                (double)c->n / (double)c->sample_rate;
 }
 /* float64 row edges in DFT-bin units (rows+1): what eo_frames_f64 and the exact mode (emspec_exact.c) compare against */

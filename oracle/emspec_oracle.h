@@ -64,6 +64,8 @@ int eo_max_threads(void);
 
 /* float64 row edges in DFT-bin units (rows+1 doubles): the table eo_frames_f64 and the exact mode compare against */
 int eo_edges64(const eo_cfg* c, double* edges);
+/* ratio^x by the specified evaluation the row edges are built with (no libm) */
+double eo_spec_pow(double ratio, double x);
 
 /* ---- EXACT mode (emspec_exact.c): the binary64 bit model of EMSPEC_MODE_EXACT ----
  * eo_frames_exact: per-bin power (double), absolute column, row and the bin's fixed-point energy q
