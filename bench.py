@@ -797,11 +797,12 @@ def main():
             measure("64 streams, FFT 1024, hop 256, reassignment ON", 64, 1 << 20, 1024, 256, True, 5)
             # EXACT mode (binary64 + 64-bit fixed point: indices equal to a float64 implementation, bytes reproducible) on
             # a second engine: configs[2] itself (64 streams; one fused kernel since round 4, no workspace) and configs[4] on
-            # 8 streams (N = 16384 still runs the two-kernel records path: 1.2 GB of workspace per stream)
+            # all 64 streams (N = 16384 runs the two-kernel records path, streams in chunks of the record workspace)
             xeng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT)
             xname = "EXACT mode, configs[2]: 64 streams, FFT 4096, hop 256, reassignment ON"
+            x4name = "EXACT mode, configs[4]: 64 streams, FFT 16384, hop 512, reassignment ON"
             for name, Sx, nx, hx, reps in ((xname, 64, 4096, 256, 3),
-                                           ("EXACT mode, configs[4] shape: 8 streams, FFT 16384, hop 512, reassignment ON", 8, 16384, 512, 2)):
+                                           (x4name, 64, 16384, 512, 2)):
                 Cx = emspec.num_columns(L, nx, hx)
                 px = pcm[:Sx].contiguous()
                 dbx = db.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
@@ -813,6 +814,11 @@ def main():
             if px_:
                 cfgs[xname]["roofline"]["traffic"] = px_.get("hbm_bytes_per_launch") if fx_ else None
                 cfgs[xname]["roofline"]["traffic_source"] = f"{px_['file']}{'' if fx_ else ' (STALE: kernels changed since, withheld)'}"
+            px4, fx4 = profile_for("exact_n16384", lib_sha)
+            if px4:
+                cfgs[x4name]["roofline"]["traffic"] = px4.get("hbm_bytes_per_launch") if fx4 else None
+                cfgs[x4name]["roofline"]["traffic_source"] = f"{px4['file']}{'' if fx4 else ' (STALE: kernels changed since, withheld)'}"
+                cfgs[x4name]["kernel_split"] = px4.get("kernel_split") if fx4 else None
             xeng.device_status()      # a protocol error of the fused kernels' bounded waits would surface here
             xeng.close()
             if not args.no_cpu_baseline:

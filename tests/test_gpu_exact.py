@@ -405,6 +405,46 @@ def test_exact_full_size_spot_checks_against_bit_model(xengine):
     assert chk == (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))
 
 
+def test_exact_n16384_full_size_spot_checks_against_bit_model(xengine):
+    """BASELINE configs[4] as named, in EXACT mode: 64 streams x 2^22 samples, FFT 16384, hop 512 (522,304 columns).  This
+    shape runs the two-kernel records path with the streams in chunks of the record workspace (12 B per bin: ~0.8 GB per
+    stream, so a 4 GiB workspace takes five streams at a time) - the spot checks sit on both sides of stream-chunk
+    boundaries, on the first / last columns of streams, on both sides of scatter-tile boundaries and at random cells, each
+    against the binary64 bit model evaluated on the slice of audio that can reach the column (frames c-16 .. c+16):
+    array_equal on the dB bits and the palette index; a second run gives the same bytes."""
+    import torch
+    n, hop, D = 16384, 512, 16
+    S, L = 64, 1 << 22
+    base = synth.streams(4, L)
+    rng = np.random.default_rng(1638)
+    pcm = np.stack([np.roll(base[s % 4], 2311 * s) * (0.4 + 0.6 * ((s * 5) % 7) / 6) for s in range(S)]).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pcm).to(dev)
+    Cn = (L - n) // hop + 1
+    assert S * Cn == 522304
+    db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+    idx = torch.empty((S, Cn, 1024), dtype=torch.uint8, device=dev)
+    assert not xengine.fused(n, hop, True)
+    xengine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    cfg = O.make_cfg(n, hop, True)
+    # (stream, column): every stream next to a possible chunk boundary (chunks of 1..8 streams all put one between two of
+    # these), the ends of streams, multiples of 16 and 32 columns +- 1 (scatter tiles), random cells
+    cells = [(s, c) for s in (0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 15, 16, 31, 32, 63) for c in (0, Cn - 1)]
+    cells += [(int(rng.integers(0, S)), c) for c in (15, 16, 17, 31, 32, 33, 4095, 4096, 4097, Cn - 17, Cn - 16)]
+    cells += [(int(rng.integers(0, S)), int(rng.integers(40, Cn - 40))) for _ in range(12)]
+    for s, c in cells:
+        f0, f1 = max(0, c - D), min(Cn - 1, c + D)
+        odb, _, oidx, _ = O.batch_exact(cfg, pcm[s, f0 * hop:f1 * hop + n][None], want=("db", "index"), threads=1)
+        assert np.array_equal(db[s, c].cpu().numpy().view(np.uint32), odb[0, c - f0].view(np.uint32)), f"dB bits differ at stream {s} column {c}"
+        assert np.array_equal(idx[s, c].cpu().numpy(), oidx[0, c - f0]), f"index differs at stream {s} column {c}"
+    chk = (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))
+    db.zero_(); idx.zero_()
+    xengine.batch_device(x, n, hop, True, db=db, index=idx)
+    torch.cuda.synchronize()
+    assert chk == (int(idx.sum(dtype=torch.int64).item()), float(db.double().sum().item()))
+
+
 @pytest.mark.parametrize("n,hop,S,frames", [(16384, 512, 5, 70), (8192, 512, 4, 90), (4096, 128, 3, 120)])
 def test_exact_record_path_stream_chunks(n, hop, S, frames, monkeypatch):
     """The shapes that still run as two kernels with per-bin records in HBM (N != 4096, or N = 4096 at a hop whose u64 ring does
