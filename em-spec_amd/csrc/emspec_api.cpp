@@ -239,7 +239,7 @@ PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign) {
     // runs neighbouring stream-chunks on two HIP streams): two fused launches share the chip, so segments are capped at
     // 1,024 columns (a one-round plan of very long workgroups would degenerate into two rounds); the chunks of that pipeline
     // are small (96 MB of staging), so their segments are short anyway and keep the exclusive plan's low halo.
-    d.shared = comm_shares_device(e) ? 1 : (e->two_lanes ? 2 : 0);
+    d.shared = comm_shares_device(e) ? 1 : 0;
     return d;
 }
 
@@ -352,9 +352,12 @@ void emspec_destroy(emspec_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    if (e->stream_in) (void)hipStreamSynchronize(e->stream_in);
+    if (e->stream_out) (void)hipStreamSynchronize(e->stream_out);
     comm_destroy(e);
     drop_plans(e);
+    (void)hipFree(e->d_xlow);
+    if (e->xlow_event) (void)hipEventDestroy(e->xlow_event);
     (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
     (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
     (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak); (void)hipFree(e->d_pstate);
@@ -363,7 +366,11 @@ void emspec_destroy(emspec_engine* e) {
     if (e->h_coldb) (void)hipHostFree(e->h_coldb);
     if (e->h_colrgba) (void)hipHostFree(e->h_colrgba);
     if (e->stream) (void)hipStreamDestroy(e->stream);
-    if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->stream_in) (void)hipStreamDestroy(e->stream_in);
+    if (e->stream_out) (void)hipStreamDestroy(e->stream_out);
+    for (auto& ev : e->pipe_ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->h_hdr) (void)hipHostFree(e->h_hdr);
+    (void)hipFree(e->d_packscratch);
     delete e;
 }
 
@@ -385,13 +392,31 @@ int emspec_device_status(emspec_engine* e) {
     return EMSPEC_OK;
 }
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
+}  // extern "C"
+// EXACT mode, N = 4096: rows of the ring that the no-parking kernel (exact_fused_lr.hip.inc) keeps in global memory, or -1
+// when it does not serve this engine's shape or axis.  The axis is served when at most 6 % of a frame's bins lie below row
+// rl (on the default log axis at hop 256: rl = 440 of 1024 rows, 36 of 2,049 bins); each of those costs a device-scope
+// atomic, so a linear axis (44 % of the bins there) stays on round 4's kernel, which parks instead.
+static int exact_lr_rows(const emspec_engine* e, int n, const ExactPlanDev& pd) {
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_EXACT_PARKED")) { if (ev[0] == '1') return -1; }   // A/B aid: round 4's kernel
+#endif
+    const int rl = exact_fused_lr_low_rows(n, pd);
+    if (rl <= 0) return rl;
+    const double hz = e->custom_edges_hz.empty()
+                          ? (double)e->cfg.fmin_hz * spec_pow((double)e->cfg.fmax_hz / (double)e->cfg.fmin_hz, (double)rl / (double)e->cfg.rows)
+                          : (double)e->custom_edges_hz[rl];
+    const double share = hz / ((double)e->cfg.sample_rate * 0.5);
+    return share <= 0.06 ? rl : -1;
+}
+extern "C" {
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign) {
     if (!e || n < 1 || hop < 1) return 0;
     if (e->exact()) {   // only the shape decides (exact_fused_supported reads rows and D)
         ExactPlanDev pd{};
         pd.rows = e->cfg.rows;
         pd.D = latency(n, hop, reassign);
-        return exact_fused_supported(n, pd) ? 1 : 0;
+        return (exact_lr_rows(e, n, pd) >= 0 || exact_fused_supported(n, pd)) ? 1 : 0;
     }
     return fused_supported(n, hop, e->cfg.rows, reassign) ? 1 : 0;
 }
@@ -552,6 +577,22 @@ static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, cons
     return EMSPEC_OK;
 }
 
+// The low-row scratch of the no-parking EXACT kernel: grown on demand; a launch on another HIP stream than the previous one
+// waits for it (one scratch per engine: two launches must not run side by side on it)
+static int exact_lr_prepare(emspec_engine* e, const ExactPlanDev& pd, int rl, int S, int64_t C, hipStream_t st) {
+    if (rl <= 0) return EMSPEC_OK;
+    int rc;
+    const size_t need = exact_fused_lr_scratch_bytes(pd, rl, S, C);
+    if (need > e->xlow_bytes) {
+        if (e->xlow_used) HIPCHK(e, hipEventSynchronize(e->xlow_event));      // the old buffer may still be in use
+        if ((rc = grow(e, (void**)&e->d_xlow, &e->xlow_bytes, need))) return rc;
+    }
+    if (!e->xlow_event) HIPCHK(e, hipEventCreateWithFlags(&e->xlow_event, hipEventDisableTiming));
+    if (e->xlow_used) HIPCHK(e, hipStreamWaitEvent(st, e->xlow_event, 0));
+    e->xlow_used = true;
+    return EMSPEC_OK;
+}
+
 // EXACT mode: per-bin (q, key) records (exact_frames_kernel) -> u64 LDS tiles (exact_tile_scatter_kernel), in chunks of
 // streams so the record workspace stays bounded
 static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop,
@@ -559,7 +600,14 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     int rc;
     const ExactPlanDev pd = exact_plan_dev(e, p, hop, reassign);
     const ExactDbMap m = exact_db_map(e, n, pd);
-    if (exact_fused_supported(n, pd)) {   // one kernel, no records (exact_fused.hip.inc)
+    const int rl = exact_lr_rows(e, n, pd);
+    if (rl >= 0) {   // one kernel, no records, no parking (exact_fused_lr.hip.inc)
+        if ((rc = exact_lr_prepare(e, pd, rl, S, C, st))) return rc;
+        HIPCHK(e, launch_exact_fused_lr(n, pd, m, e->d_lut, pcm, L, S, C, rl, e->d_xlow, e->xlow_bytes, db, rgba, index, st));
+        if (rl > 0) HIPCHK(e, hipEventRecord(e->xlow_event, st));
+        return EMSPEC_OK;
+    }
+    if (exact_fused_supported(n, pd)) {   // one kernel with the ring parked under the planes (exact_fused.hip.inc): any axis
         HIPCHK(e, launch_exact_fused(n, pd, m, e->d_lut, pcm, L, S, C, db, rgba, index, st));
         return EMSPEC_OK;
     }
@@ -705,9 +753,26 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
     if ((rc = get_plan(e, n, &p))) return rc;
     if (e->exact()) {   // the stamped build of exact_fused4096_kernel (waves: 16; slots: exact_fused.hip.inc)
         const ExactPlanDev xpd = exact_plan_dev(e, *p, hop, reassign);
-        if (!exact_fused_supported(n, xpd)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused exact kernel for this shape");
         const ExactDbMap xm = exact_db_map(e, n, xpd);
         const int64_t Cx = emspec_num_columns(L, n, hop);
+        const int xrl = exact_lr_rows(e, n, xpd);
+        if (xrl >= 0) {   // the stamped build of exact_fused4096_lr_kernel (slots: exact_fused_lr.hip.inc)
+            if ((rc = exact_lr_prepare(e, xpd, xrl, S, Cx, e->stream))) return rc;
+            HIPCHK(e, launch_exact_fused_lr(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, xrl, e->d_xlow, e->xlow_bytes, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
+            if (waves) *waves = 16;
+            if (!cycles) return EMSPEC_OK;
+            unsigned long long* dl = nullptr;
+            const size_t lbytes = (size_t)(*groups) * 16 * 8 * sizeof(unsigned long long);
+            HIPCHK(e, hipMalloc(&dl, lbytes));
+            hipError_t lr = launch_exact_fused_lr(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, xrl, e->d_xlow, e->xlow_bytes, db_dev, nullptr, index_dev, e->stream, dl, groups);
+            if (lr == hipSuccess && xrl > 0) lr = hipEventRecord(e->xlow_event, e->stream);
+            if (lr == hipSuccess) lr = hipMemcpyAsync(cycles, dl, lbytes, hipMemcpyDeviceToHost, e->stream);
+            if (lr == hipSuccess) lr = hipStreamSynchronize(e->stream);
+            (void)hipFree(dl);
+            HIPCHK(e, lr);
+            return EMSPEC_OK;
+        }
+        if (!exact_fused_supported(n, xpd)) return fail(e, EMSPEC_ERR_INVALID_ARG, "no fused exact kernel for this shape");
         HIPCHK(e, launch_exact_fused(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
         if (waves) *waves = 16;
         if (!cycles) return EMSPEC_OK;
@@ -740,6 +805,153 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
 }
 #endif  // EMSPEC_DIAG
 
+}  // extern "C"
+
+// ---- host-buffer batch: a three-stage pipeline over chunks of streams.  H2D copies on their own HIP stream, every kernel on
+// the engine's compute stream (so the per-engine workspaces - EXACT records / low-row scratch, display post-process - are
+// used by one launch at a time, and no two fused launches share the chip), D2H copies on a third stream; kPipeSets staging
+// sets, events between the stages.  PCIe is full duplex: the H2D of chunk k+1, the kernels of chunk k and the D2H of chunk
+// k-1 are in flight together.  With `pk` the palette-index columns leave the device as the gather's lossless wire image
+// (pack.hip.inc: ~186 B instead of 1,024 B per column on the bench input), one image per stream, tightly packed into the
+// caller's buffer in stream order; the host learns each image's size from its 32-byte header, which is copied out behind the
+// pack, so the D2H stage of a chunk is enqueued kPipeLag chunks after its kernels.
+struct PackedOut { uint8_t* wire; int64_t capacity; int64_t* offsets; };
+static constexpr int kPipeSets = 3, kPipeLag = 2;
+
+static int pipe_setup(emspec_engine* e) {
+    if (!e->stream_in) HIPCHK(e, hipStreamCreateWithFlags(&e->stream_in, hipStreamNonBlocking));
+    if (!e->stream_out) HIPCHK(e, hipStreamCreateWithFlags(&e->stream_out, hipStreamNonBlocking));
+    for (int i = 0; i < 3 * kPipeSets; ++i)
+        if (!e->pipe_ev[i]) HIPCHK(e, hipEventCreateWithFlags(&e->pipe_ev[i], hipEventDisableTiming));
+    return EMSPEC_OK;
+}
+
+static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                          const emspec_out* out, const PackedOut* pk) {
+    int rc;
+    if ((rc = pipe_setup(e))) return rc;
+    const int64_t C = emspec_num_columns(L, n, hop);
+    const int R = e->cfg.rows;
+    const size_t col_cells = (size_t)C * R;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t in_s = (size_t)L * sizeof(float);
+    const size_t db_s = (out && out->db) ? col_cells * 4 : 0, rgba_s = (out && out->rgba) ? col_cells * 4 : 0;
+    const size_t idx_s = ((out && out->index) || pk) ? col_cells : 0;
+    const size_t wire_s = pk ? (size_t)wire_bound_bytes(C, R) : 0;
+    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s) + al(wire_s);
+    // chunks: about sixteen per batch (pipeline fill and drain stay small beside the steady state), bounded by 1 GiB of
+    // staging per set; a chunk of a few streams still fills the chip (segments are cut per launch)
+    int chunk = (S + 15) / 16;
+    const int fit = (int)(((size_t)1 << 30) / per_stream);
+    chunk = chunk > fit ? fit : chunk;
+    chunk = chunk < 1 ? 1 : chunk;
+    const size_t set_bytes = (size_t)chunk * per_stream;
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, kPipeSets * set_bytes + 1024))) return rc;
+    if (pk) {
+        if ((rc = grow(e, (void**)&e->d_packscratch, &e->packscratch_bytes, wire_scratch_bytes(C)))) return rc;
+        const size_t hb = (size_t)kPipeSets * chunk * 32;
+        if (hb > e->h_hdr_bytes) {
+            if (e->h_hdr) (void)hipHostFree(e->h_hdr);
+            e->h_hdr = nullptr; e->h_hdr_bytes = 0;
+            HIPCHK(e, hipHostMalloc((void**)&e->h_hdr, hb, hipHostMallocDefault));
+            e->h_hdr_bytes = hb;
+        }
+        pk->offsets[0] = 0;
+    }
+    hipEvent_t* ev_in = e->pipe_ev;
+    hipEvent_t* ev_comp = e->pipe_ev + kPipeSets;
+    hipEvent_t* ev_out = e->pipe_ev + 2 * kPipeSets;
+    const int nchunks = (S + chunk - 1) / chunk;
+    struct Set { float* pcm; float* db; uint8_t* rgba; uint8_t* idx; uint8_t* wire; };
+    auto set_of = [&](int b) {
+        char* base = e->d_stage + (size_t)b * set_bytes;
+        Set q;
+        q.pcm = (float*)base; base += al(in_s) * chunk;
+        q.db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
+        q.rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
+        q.idx = idx_s ? (uint8_t*)base : nullptr; base += al(idx_s) * chunk;
+        q.wire = wire_s ? (uint8_t*)base : nullptr;
+        return q;
+    };
+    hipError_t herr = hipSuccess;
+    rc = EMSPEC_OK;
+    std::string why;
+    // the D2H stage of chunk f (its kernels are enqueued; with pk: wait for them, then the images' sizes are known)
+    auto drain = [&](int f) {
+        const int b = f % kPipeSets, s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const Set q = set_of(b);
+        if (!pk) {
+            herr = hipStreamWaitEvent(e->stream_out, ev_comp[b], 0);
+            if (herr == hipSuccess && db_s) herr = hipMemcpyAsync(out->db + (size_t)s0 * col_cells, q.db, db_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba + 4 * (size_t)s0 * col_cells, q.rgba, rgba_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index + (size_t)s0 * col_cells, q.idx, idx_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+        } else {
+            herr = hipEventSynchronize(ev_comp[b]);
+            for (int i = 0; i < sc && herr == hipSuccess && rc == EMSPEC_OK; ++i) {
+                const uint32_t* h = reinterpret_cast<const uint32_t*>(e->h_hdr + ((size_t)b * chunk + i) * 32);
+                const uint64_t hcols = (uint64_t)h[2] | ((uint64_t)h[3] << 32), hpay = (uint64_t)h[4] | ((uint64_t)h[5] << 32);
+                if (h[0] != 0x32574D45u || (int32_t)h[1] != R || hcols != (uint64_t)C || hpay > (uint64_t)col_cells) {
+                    rc = EMSPEC_ERR_HIP; why = "the packed image of a stream carries a bad header"; break;
+                }
+                const int64_t bytes = wire_fixed_bytes(C, R) + (int64_t)((hpay + 15) & ~(uint64_t)15);
+                const int64_t at = pk->offsets[s0 + i];
+                if (at + bytes > pk->capacity) {
+                    rc = EMSPEC_ERR_INVALID_ARG;
+                    why = "wire buffer too small (emspec_wire_bound(columns, rows) per stream always suffices)";
+                    break;
+                }
+                herr = hipMemcpyAsync(pk->wire + at, q.wire + (size_t)i * al(wire_s), (size_t)bytes, hipMemcpyDeviceToHost, e->stream_out);
+                pk->offsets[s0 + i + 1] = at + bytes;
+            }
+        }
+        if (herr == hipSuccess && rc == EMSPEC_OK) herr = hipEventRecord(ev_out[b], e->stream_out);
+    };
+    int drained = 0;
+    for (int ci = 0; ci < nchunks && rc == EMSPEC_OK && herr == hipSuccess; ++ci) {
+        const int b = ci % kPipeSets, s0 = ci * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const Set q = set_of(b);
+        // stage 1: samples in (the set's input is free once the kernels of chunk ci - kPipeSets are done)
+        if (ci >= kPipeSets) herr = hipStreamWaitEvent(e->stream_in, ev_comp[b], 0);
+        if (herr == hipSuccess) herr = hipMemcpyAsync(q.pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, e->stream_in);
+        if (herr == hipSuccess) herr = hipEventRecord(ev_in[b], e->stream_in);
+        // stage 2: kernels (the set's outputs are free once chunk ci - kPipeSets has been copied out)
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(e->stream, ev_in[b], 0);
+        if (herr == hipSuccess && ci >= kPipeSets) herr = hipStreamWaitEvent(e->stream, ev_out[b], 0);
+        if (herr != hipSuccess) break;
+        rc = emspec_batch_device(e, q.pcm, sc, L, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
+        if (rc != EMSPEC_OK) break;
+        if (pk) {
+            for (int i = 0; i < sc && herr == hipSuccess; ++i) {
+                uint8_t* w = q.wire + (size_t)i * al(wire_s);
+                herr = launch_wire_pack(q.idx + (size_t)i * col_cells, C, R, w, e->d_packscratch, e->stream);
+                if (herr == hipSuccess) herr = hipMemcpyAsync(e->h_hdr + ((size_t)b * chunk + i) * 32, w, 32, hipMemcpyDeviceToHost, e->stream);
+            }
+        }
+        if (herr == hipSuccess) herr = hipEventRecord(ev_comp[b], e->stream);
+        // stage 3, kPipeLag chunks behind when the host has to read the sizes first
+        const int lag = pk ? kPipeLag : 0;
+        while (herr == hipSuccess && rc == EMSPEC_OK && drained <= ci - lag) drain(drained++);
+    }
+    while (herr == hipSuccess && rc == EMSPEC_OK && drained < nchunks) drain(drained++);
+    const hipError_t s1 = hipStreamSynchronize(e->stream_in), s2 = hipStreamSynchronize(e->stream), s3 = hipStreamSynchronize(e->stream_out);
+    if (rc != EMSPEC_OK) return why.empty() ? rc : fail(e, rc, why);
+    HIPCHK(e, herr);
+    HIPCHK(e, s1);
+    HIPCHK(e, s2);
+    HIPCHK(e, s3);
+    if (read_kernel_error(true) > 0) return fail(e, EMSPEC_ERR_HIP, "a kernel's bounded wait timed out (protocol error): results invalid");
+    return EMSPEC_OK;
+}
+
+static bool host_pinned(const void* p) {
+    if (!p) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+extern "C" {
+
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
                  const emspec_out* out) {
     if (!e || !pcm || !out) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
@@ -747,67 +959,84 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     if (rc) return rc;
     if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
     HIPCHK(e, hipSetDevice(e->device));
+    if (!out->db && !out->rgba && !out->index) return EMSPEC_OK;
+    // The copies reach PCIe speed only from pinned memory: callers that care get it from emspec_host_alloc (pinning the
+    // caller's pageable buffers per call costs more than it saves: measured 49 ms vs 27 ms for 670 MB).  Pageable copies are
+    // staged synchronously by the runtime, so chunking only adds overhead there: one chunk, one stream.
+    if (S > 1 && host_pinned(pcm) && host_pinned(out->db) && host_pinned(out->rgba) && host_pinned(out->index))
+        return batch_pipeline(e, pcm, S, L, n, hop, reassign, out, nullptr);
     const int64_t C = emspec_num_columns(L, n, hop);
-    const size_t col_cells = (size_t)C * e->cfg.rows;          // cells per stream
-    const size_t in_s = (size_t)L * sizeof(float);              // bytes per stream, each buffer
+    const size_t col_cells = (size_t)C * e->cfg.rows;
+    const size_t in_s = (size_t)L * sizeof(float);
     const size_t db_s = out->db ? col_cells * 4 : 0, rgba_s = out->rgba ? col_cells * 4 : 0, idx_s = out->index ? col_cells : 0;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-
-    // Chunks of streams are pipelined on two HIP streams so H2D, compute and D2H of neighbouring
-    // chunks overlap.  The copies reach PCIe speed only from pinned memory: callers that care get it
-    // from emspec_host_alloc (pinning the caller's pageable buffers per call costs more than it saves:
-    // measured 49 ms vs 27 ms for 670 MB).
-    auto unpin = []() {};
-    auto is_pinned = [](const void* p) {
-        if (!p) return true;
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-        return at.type == hipMemoryTypeHost;
-    };
-    const bool pinned = is_pinned(pcm) && is_pinned(out->db) && is_pinned(out->rgba) && is_pinned(out->index);
-    // pageable copies are staged synchronously by the runtime: chunking only adds overhead there;
-    // the generic path shares one record workspace, so it stays on one stream too
-    // ... and so does the display post-process (raw dB / peak / post workspaces are per engine, not per lane)
-    const bool display = e->smoothing > 0.0f || e->agc > 0.0f;
-    // ... and the EXACT mode (one record workspace per engine)
-    const bool two = pinned && !e->exact() && fused_supported(n, hop, e->cfg.rows, reassign) && S > 1 && !display;
-    if (two && !e->stream2 && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
-        unpin();
-        return fail(e, EMSPEC_ERR_HIP, "hipStreamCreate failed");
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, (size_t)S * (al(in_s) + al(db_s) + al(rgba_s) + al(idx_s)) + 1024))) return rc;
+    char* base = e->d_stage;
+    float* d_pcm = (float*)base; base += al(in_s) * S;
+    float* d_db = db_s ? (float*)base : nullptr; base += al(db_s) * S;
+    uint8_t* d_rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * S;
+    uint8_t* d_idx = idx_s ? (uint8_t*)base : nullptr;
+    hipStream_t st = e->stream;
+    hipError_t herr = hipMemcpyAsync(d_pcm, pcm, in_s * S, hipMemcpyHostToDevice, st);
+    if (herr == hipSuccess) {
+        rc = emspec_batch_device(e, d_pcm, S, L, n, hop, reassign, d_db, d_rgba, d_idx, st);
+        if (rc == EMSPEC_OK && db_s) herr = hipMemcpyAsync(out->db, d_db, db_s * S, hipMemcpyDeviceToHost, st);
+        if (rc == EMSPEC_OK && herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba, d_rgba, rgba_s * S, hipMemcpyDeviceToHost, st);
+        if (rc == EMSPEC_OK && herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index, d_idx, idx_s * S, hipMemcpyDeviceToHost, st);
     }
-    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s);
-    int chunk = (int)(((size_t)96 << 20) / per_stream);
-    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
-    if (!two) chunk = S;
-    const int nbuf = two ? 2 : 1;
-    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, (size_t)nbuf * chunk * per_stream + 1024))) { unpin(); return rc; }
-    hipError_t herr = hipSuccess;
-    e->two_lanes = two;
-    for (int s0 = 0, ci = 0; s0 < S && rc == EMSPEC_OK && herr == hipSuccess; s0 += chunk, ++ci) {
-        const int sc = (S - s0 < chunk) ? S - s0 : chunk;
-        hipStream_t st = (two && (ci & 1)) ? e->stream2 : e->stream;
-        char* base = e->d_stage + (size_t)(ci % nbuf) * chunk * per_stream;
-        float* d_pcm = (float*)base; base += al(in_s) * chunk;
-        float* d_db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
-        uint8_t* d_rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
-        uint8_t* d_idx = idx_s ? (uint8_t*)base : nullptr;
-        herr = hipMemcpyAsync(d_pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, st);
-        if (herr != hipSuccess) break;
-        rc = emspec_batch_device(e, d_pcm, sc, L, n, hop, reassign, d_db, d_rgba, d_idx, st);
-        if (rc != EMSPEC_OK) break;
-        if (db_s) herr = hipMemcpyAsync(out->db + s0 * col_cells, d_db, db_s * sc, hipMemcpyDeviceToHost, st);
-        if (herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba + 4 * s0 * col_cells, d_rgba, rgba_s * sc, hipMemcpyDeviceToHost, st);
-        if (herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index + s0 * col_cells, d_idx, idx_s * sc, hipMemcpyDeviceToHost, st);
-    }
-    hipError_t s1 = hipStreamSynchronize(e->stream);
-    hipError_t s2 = e->stream2 ? hipStreamSynchronize(e->stream2) : hipSuccess;
-    e->two_lanes = false;
-    unpin();
+    const hipError_t s1 = hipStreamSynchronize(st);
     if (rc != EMSPEC_OK) return rc;
     HIPCHK(e, herr);
     HIPCHK(e, s1);
-    HIPCHK(e, s2);
     if (read_kernel_error(true) > 0) return fail(e, EMSPEC_ERR_HIP, "a kernel's bounded wait timed out (protocol error): results invalid");
+    return EMSPEC_OK;
+}
+
+int emspec_batch_packed(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                        uint8_t* wire, int64_t wire_capacity, int64_t* offsets) {
+    if (!e || !pcm || !wire || !offsets || wire_capacity < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
+    int rc = check_shape(e, n, hop);
+    if (rc) return rc;
+    if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
+    if ((uint64_t)emspec_num_columns(L, n, hop) * (uint64_t)e->cfg.rows >= (1ull << 32))
+        return fail(e, EMSPEC_ERR_INVALID_ARG, "at most 2^32 cells per stream");
+    if (e->cfg.rows % 4) return fail(e, EMSPEC_ERR_INVALID_ARG, "the wire image needs rows % 4 == 0");
+    HIPCHK(e, hipSetDevice(e->device));
+    const PackedOut pk{wire, wire_capacity, offsets};
+    return batch_pipeline(e, pcm, S, L, n, hop, reassign, nullptr, &pk);
+}
+
+int emspec_wire_unpack_host(const uint8_t* wire, int64_t wire_bytes, int64_t columns, int32_t rows, uint8_t* index_out) {
+    if (!wire || !index_out || columns < 1 || rows < 1 || wire_bytes < 32) return EMSPEC_ERR_INVALID_ARG;
+    uint32_t h[8];
+    memcpy(h, wire, 32);
+    const uint64_t hcols = (uint64_t)h[2] | ((uint64_t)h[3] << 32), hpay = (uint64_t)h[4] | ((uint64_t)h[5] << 32);
+    const int mw = (rows + 31) >> 5;
+    const int64_t fixed = 32 + columns * 4 + columns * (int64_t)mw * 4;
+    if (h[0] != 0x32574D45u || (int32_t)h[1] != rows || hcols != (uint64_t)columns || hpay > (uint64_t)columns * (uint64_t)rows ||
+        wire_bytes < fixed + (int64_t)hpay)
+        return EMSPEC_ERR_INVALID_ARG;
+    const uint8_t* offp = wire + 32;
+    const uint8_t* maskp = offp + columns * 4;
+    const uint8_t* pay = wire + fixed;
+    for (int64_t c = 0; c < columns; ++c) {
+        uint32_t off;
+        memcpy(&off, offp + c * 4, 4);
+        uint8_t* dst = index_out + c * (int64_t)rows;
+        memset(dst, 0, (size_t)rows);
+        uint64_t at = off;
+        for (int w = 0; w < mw; ++w) {
+            uint32_t m;
+            memcpy(&m, maskp + (c * mw + w) * 4, 4);
+            while (m) {
+                const int bit = __builtin_ctz(m);
+                m &= m - 1;
+                const int r = w * 32 + bit;
+                if (r >= rows || at >= hpay) return EMSPEC_ERR_INVALID_ARG;   // a damaged image must not write or read out of range
+                dst[r] = pay[at++];
+            }
+        }
+    }
     return EMSPEC_OK;
 }
 

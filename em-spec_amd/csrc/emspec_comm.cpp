@@ -40,12 +40,7 @@
 using namespace emspec;
 
 namespace emspec {
-int64_t wire_bound_bytes(int64_t columns, int rows);
-size_t wire_scratch_bytes(int64_t columns);
 uint64_t* wire_total_ptr(void* scratch, int64_t columns);
-hipError_t launch_wire_pack(const uint8_t* index, int64_t columns, int rows, uint8_t* wire, void* scratch, hipStream_t st);
-hipError_t launch_wire_unpack(const uint8_t* wire, int64_t columns, int rows, uint8_t* index, hipStream_t st);
-int64_t wire_fixed_bytes(int64_t columns, int rows);
 }  // namespace emspec
 
 #ifdef EMSPEC_DIAG

@@ -28,8 +28,12 @@ struct emspec_engine {
     emspec_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second lane of the host-buffer batch pipeline
-    bool two_lanes = false;          // emspec_batch is running chunks on both lanes: fused launches use the shared-device segment plan
+    // host-buffer batch pipeline (emspec_batch / emspec_batch_packed): H2D and D2H copy streams beside the compute stream,
+    // [in | computed | out] events per staging set, the packed images' headers in pinned host memory
+    hipStream_t stream_in = nullptr, stream_out = nullptr;
+    hipEvent_t pipe_ev[9] = {};
+    uint8_t* h_hdr = nullptr; size_t h_hdr_bytes = 0;
+    void* d_packscratch = nullptr; size_t packscratch_bytes = 0;
     std::string arch;
     mutable std::string err;
     std::map<int, emspec::Plan> plans;
@@ -39,6 +43,12 @@ struct emspec_engine {
     float* d_hist = nullptr;
     size_t hist_bytes = 0;
     bool exact() const { return cfg.mode == EMSPEC_MODE_EXACT; }
+    // EXACT fused kernel (exact_fused_lr.hip.inc): the ring's low rows, [workgroup][slots][rl] u64; launches that use it
+    // are serialised across HIP streams through xlow_event
+    unsigned long long* d_xlow = nullptr;
+    size_t xlow_bytes = 0;
+    hipEvent_t xlow_event = nullptr;
+    bool xlow_used = false;
     char* d_stage = nullptr;
     size_t stage_bytes = 0;
     // streaming state

@@ -60,6 +60,15 @@ bool exact_fused_supported(int n, const ExactPlanDev& pl);
 hipError_t launch_exact_fused(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
                               int64_t L, int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
                               unsigned long long* stamps = nullptr, int64_t* stamp_groups = nullptr);
+// EXACT mode, one kernel without parking (exact_fused_lr.hip.inc): the ring's rows >= rl in LDS beside the planes, rows < rl
+// in a per-workgroup scratch in global memory (device-scope atomics only).  exact_fused_lr_low_rows: rl for the shape
+// (rows, D), or -1 when the shape is not served; whether the AXIS is (few bins below row rl) is the caller's decision.
+int exact_fused_lr_low_rows(int n, const ExactPlanDev& pl);
+size_t exact_fused_lr_scratch_bytes(const ExactPlanDev& pl, int rl, int S, int64_t C);
+hipError_t launch_exact_fused_lr(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
+                                 int64_t L, int S, int64_t C, int rl, unsigned long long* low, size_t low_bytes, float* db,
+                                 uint8_t* rgba, uint8_t* index, hipStream_t st, unsigned long long* stamps = nullptr,
+                                 int64_t* stamp_groups = nullptr);
 hipError_t launch_exact_finalize(const unsigned long long* cells, int64_t ncells, const ExactDbMap& m, const uint8_t* lut,
                                  float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
 
@@ -93,6 +102,12 @@ hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uin
                               float* gain, hipStream_t st);
 hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut,
                               uint8_t* rgba, float* state, float* yprev, hipStream_t st);
+// the gather's wire image (pack.hip.inc)
+int64_t wire_bound_bytes(int64_t columns, int rows);
+int64_t wire_fixed_bytes(int64_t columns, int rows);
+size_t wire_scratch_bytes(int64_t columns);
+hipError_t launch_wire_pack(const uint8_t* index, int64_t columns, int rows, uint8_t* wire, void* scratch, hipStream_t st);
+hipError_t launch_wire_unpack(const uint8_t* wire, int64_t columns, int rows, uint8_t* index, hipStream_t st);
 bool fused_supported(int n, int hop, int rows, int reassign);
 int device_cus();           // compute units of the current device
 #ifdef EMSPEC_DIAG          // diagnostic build only (libemspec_diag.so, include/emspec_debug.h)

@@ -655,3 +655,4 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
 #include "pack.hip.inc"
 #include "exact.hip.inc"
 #include "exact_fused.hip.inc"
+#include "exact_fused_lr.hip.inc"

@@ -36,7 +36,7 @@ SYMBOLS = [
     "emspec_comm_unique_id", "emspec_comm_init", "emspec_comm_destroy", "emspec_comm_rank", "emspec_comm_world",
     "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
     "emspec_parity_dump_exact", "emspec_gather_packed_layout", "emspec_mode", "emspec_build_info", "emspec_device_status",
-    "emspec_comm_set_timeout",
+    "emspec_comm_set_timeout", "emspec_batch_packed", "emspec_wire_unpack_host",
 ]
 
 
@@ -48,6 +48,20 @@ class Config(C.Structure):
 
 class Out(C.Structure):
     _fields_ = [("db", C.c_void_p), ("rgba", C.c_void_p), ("index", C.c_void_p)]
+
+
+def wire_unpack_host(image, columns, rows, out=None, diag=False):
+    """Expand one wire image (numpy uint8) into palette indices [columns, rows] on the host's own cores
+    (emspec_wire_unpack_host: plain C, no device, no engine)."""
+    image = np.ascontiguousarray(image, np.uint8)
+    if out is None:
+        out = np.empty((columns, rows), np.uint8)
+    assert out.dtype == np.uint8 and out.flags.c_contiguous and out.size == columns * rows
+    lib = load(diag=diag)
+    rc = lib.emspec_wire_unpack_host(_np_ptr(image), C.c_int64(image.size), C.c_int64(columns), C.c_int32(rows), _np_ptr(out))
+    if rc != 0:
+        raise EmspecError(rc, "emspec_wire_unpack_host: the image does not match (columns, rows) or is damaged")
+    return out
 
 
 class EmspecError(RuntimeError):
@@ -321,6 +335,22 @@ class Engine:
         out = Out(_np_ptr(db), _np_ptr(rgba), _np_ptr(idx))
         self._chk(self._lib.emspec_batch(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), C.byref(out)))
         return {"db": db, "rgba": rgba, "index": idx}
+
+    def batch_packed(self, pcm, n, hop, reassign=True, wire=None):
+        """Host buffers in, the palette-index columns out as ONE lossless wire image per stream (emspec_batch_packed):
+        returns (wire uint8 array, offsets int64 [S+1]); stream s is wire[offsets[s]:offsets[s+1]], expand it with
+        wire_unpack_host(image, columns, rows).  `wire`: optional preallocated (pinned) uint8 array."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None]
+        S, L = pcm.shape
+        Cn = num_columns(L, n, hop)
+        if wire is None:
+            wire = np.empty(S * wire_bound(Cn, self.rows), np.uint8)
+        offsets = np.zeros(S + 1, np.int64)
+        self._chk(self._lib.emspec_batch_packed(self._h, _np_ptr(pcm), S, L, n, hop, int(bool(reassign)), _np_ptr(wire),
+                                                C.c_int64(wire.size), offsets.ctypes.data_as(C.c_void_p)))
+        return wire, offsets
 
     # -- batch, device-resident torch tensors ---------------------------------
     def batch_device(self, pcm_t, n, hop, reassign=True, db=None, rgba=None, index=None, stream=None):

@@ -326,6 +326,69 @@ static napi_value Batch(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* batchPacked(handle, pcm:Float32Array(S*L), S, L, fftSize, hop, reassign, wire:Uint8Array, offsets:Float64Array(S+1)) -> columns
+ * per stream.  emspec_batch_packed: the palette-index columns cross PCIe as one lossless wire image per stream; stream s
+ * is wire.subarray(offsets[s], offsets[s+1]) (offsets as doubles: exact below 2^53). */
+static napi_value BatchPacked(napi_env env, napi_callback_info info) {
+    size_t argc = 9; napi_value argv[9];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 9) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "batchPacked(handle, pcm, S, L, fftSize, hop, reassign, wire, offsets)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* pcm; size_t plen;
+    if (!get_typed(env, argv[1], napi_float32_array, &pcm, &plen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; int64_t L; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[3], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[6], &argv[6]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[6], &reassign));
+    if (S < 1 || L < 1 || (size_t)S * (size_t)L != plen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm.length must equal S*L"); return NULL; }
+    void *wire = NULL, *offs = NULL; size_t wlen = 0, olen = 0;
+    if (!get_typed(env, argv[7], napi_uint8_array, &wire, &wlen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "wire must be a Uint8Array"); return NULL; }
+    if (!get_typed(env, argv[8], napi_float64_array, &offs, &olen, 0) || olen != (size_t)S + 1) {
+        napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "offsets must be a Float64Array(S + 1)"); return NULL;
+    }
+    int64_t* o64 = (int64_t*)malloc(sizeof(int64_t) * ((size_t)S + 1));
+    if (!o64) { napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "out of host memory"); return NULL; }
+    int rc = emspec_batch_packed(h->e, (const float*)pcm, S, L, n, hop, reassign ? 1 : 0, (uint8_t*)wire, (int64_t)wlen, o64);
+    if (rc == EMSPEC_OK) for (int32_t i = 0; i <= S; ++i) ((double*)offs)[i] = (double)o64[i];
+    free(o64);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, emspec_num_columns(L, n, hop), &r));
+    return r;
+}
+
+/* wireUnpack(image:Uint8Array, columns, rows, out:Uint8Array(columns*rows)): emspec_wire_unpack_host (no device, no engine) */
+static napi_value WireUnpack(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 4) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "wireUnpack(image, columns, rows, out)"); return NULL; }
+    void *img = NULL, *out = NULL; size_t ilen = 0, olen = 0;
+    int64_t columns; int32_t rows;
+    if (!get_typed(env, argv[0], napi_uint8_array, &img, &ilen, 0) || !get_typed(env, argv[3], napi_uint8_array, &out, &olen, 0)) {
+        napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "image and out must be Uint8Arrays"); return NULL;
+    }
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[1], &columns));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &rows));
+    if (columns < 1 || rows < 1 || olen != (size_t)columns * (size_t)rows) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "out.length must equal columns*rows"); return NULL; }
+    if (emspec_wire_unpack_host((const uint8_t*)img, (int64_t)ilen, columns, rows, (uint8_t*)out) != EMSPEC_OK) {
+        napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "the wire image does not match (columns, rows) or is damaged"); return NULL;
+    }
+    return NULL;
+}
+
+static napi_value WireBound(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int64_t columns = 0; int32_t rows = 0;
+    if (argc < 2) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "wireBound(columns, rows)"); return NULL; }
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[0], &columns));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[1], &rows));
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, emspec_wire_bound(columns, rows), &r));
+    return r;
+}
+
 /* batchAsync(handle, pcm, S, L, fftSize, hop, reassign, outDb?, outRgba?, outIndex?) -> Promise<columns>
  * Same as batch() but the work runs on the libuv thread pool (napi_create_async_work), so the
  * renderer's JS thread is not blocked for the duration of a large batch.  The typed arrays are
@@ -600,6 +663,9 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"reset", NULL, Reset, NULL, NULL, NULL, napi_default, NULL},
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},
+        {"batchPacked", NULL, BatchPacked, NULL, NULL, NULL, napi_default, NULL},
+        {"wireUnpack", NULL, WireUnpack, NULL, NULL, NULL, napi_default, NULL},
+        {"wireBound", NULL, WireBound, NULL, NULL, NULL, napi_default, NULL},
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},
         {"setDisplay", NULL, SetDisplay, NULL, NULL, NULL, napi_default, NULL},
         {"setRowEdges", NULL, SetRowEdges, NULL, NULL, NULL, napi_default, NULL},

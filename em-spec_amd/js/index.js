@@ -65,6 +65,17 @@ class Engine {
     return native.batch(this._h, pcm, S, L, fftSize, hop, !!reassign, out.db, out.rgba, out.index);
   }
 
+  /**
+   * Throughput entry with the palette-index columns kept compressed across PCIe (emspec_batch_packed): one lossless wire
+   * image per stream, ~186 B instead of 1,024 B per column on typical audio.  wire: Uint8Array (allocPinned for full
+   * speed; S * wireBound(C, rows) always suffices), offsets: Float64Array(S + 1).  Stream s is
+   * wire.subarray(offsets[s], offsets[s + 1]); expand it on the host with unpackWire(image, C, rows, out) or keep /
+   * forward it as it is.  Returns C, the columns per stream.
+   */
+  computeColumnsPacked(pcm, S, L, fftSize, hop, reassign, wire, offsets) {
+    return native.batchPacked(this._h, pcm, S, L, fftSize, hop, !!reassign, wire, offsets);
+  }
+
   /** Same as computeColumns, off the JS thread: resolves with C.  Do not touch the arrays or this
    *  engine until the promise settles (an engine is not thread-safe). */
   computeColumnsAsync(pcm, S, L, fftSize, hop, reassign, out) {
@@ -157,6 +168,10 @@ module.exports = {
   colormapStops,
   commUniqueId: native.commUniqueId,
   numColumns: native.numColumns,
+  /** Bytes that always hold the wire image of `columns` columns of `rows` rows (emspec_wire_bound). */
+  wireBound: native.wireBound,
+  /** Expand one wire image (Uint8Array) into out: Uint8Array(columns * rows) on the host's own cores - no device, no engine. */
+  unpackWire: native.wireUnpack,
   latencyColumns: native.latencyColumns,
   /** 'emspec abi=2 sources=<sha16> arch=gfx950': what the loaded libemspec was built from. */
   buildInfo: native.buildInfo,

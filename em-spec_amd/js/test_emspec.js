@@ -67,6 +67,33 @@ function checkExactAgainstJsOracle(fftSize, hop, frames) {
 }
 
 /* ABI 2: what the loaded libemspec was built from */
+/* the packed throughput entry: one wire image per stream over PCIe, expanded on the host's own cores */
+function checkPacked() {
+  const eng = em.createEngine({ mode: 1 });          // EXACT: the two calls give the same bytes
+  const fftSize = 4096, hop = 256, frames = 60, S = 5, L = fftSize + hop * (frames - 1);
+  const R = eng.rows;
+  const pcm = new Float32Array(em.allocPinned(S * L * 4));
+  for (let s = 0; s < S; s++) pcm.set(synth(L).map((v, i) => v * (1 - 0.1 * s) * ((i + s) % 5 ? 1 : 0.7)), s * L);
+  const idx = new Uint8Array(em.allocPinned(S * frames * R));
+  eng.computeColumns(pcm, S, L, fftSize, hop, true, { index: idx });
+  const wire = new Uint8Array(em.allocPinned(S * em.wireBound(frames, R)));
+  const offs = new Float64Array(S + 1);
+  const C = eng.computeColumnsPacked(pcm, S, L, fftSize, hop, true, wire, offs);
+  if (C !== frames || offs[0] !== 0 || !(offs[S] < idx.length)) throw new Error('computeColumnsPacked: columns / offsets');
+  const out = new Uint8Array(frames * R);
+  for (let s = 0; s < S; s++) {
+    em.unpackWire(wire.subarray(offs[s], offs[s + 1]), frames, R, out);
+    for (let i = 0; i < out.length; i++) if (out[i] !== idx[s * frames * R + i]) throw new Error('packed stream ' + s + ' differs at ' + i);
+  }
+  let threw = false;
+  try { em.unpackWire(wire.subarray(0, 20), frames, R, out); } catch (e) { threw = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!threw) throw new Error('a truncated image must throw EMSPEC_ERR_INVALID_ARG');
+  threw = false;
+  try { eng.computeColumnsPacked(pcm, S, L, fftSize, hop, true, wire.subarray(0, 4096), offs); } catch (e) { threw = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!threw) throw new Error('a wire buffer that is too small must throw EMSPEC_ERR_INVALID_ARG');
+  eng.destroy();
+}
+
 function checkBuildInfo() {
   const info = em.buildInfo();
   if (!/^emspec abi=2 sources=[0-9a-f]{16} arch=gfx950$/.test(info)) throw new Error('unexpected build info: ' + info);
@@ -211,6 +238,7 @@ checkAgainstJsOracle(1024, 256, false, 40);
 checkAgainstJsOracle(4096, 256, true, 48);
 const wx = checkExactAgainstJsOracle(4096, 256, 48);
 checkGatherOneRank();
+checkPacked();
 checkBuildInfo();
 const w1 = check(1024, 256, false, 40);
 const w2 = check(4096, 256, true, 40);

@@ -378,6 +378,23 @@ int emspec_wire_pack(emspec_engine* e, const uint8_t* index_dev, int64_t columns
 int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_bytes, int64_t columns,
                        uint8_t* index_dev, void* hip_stream);
 
+/*
+ * Host-buffer batch whose palette-index columns leave the device PACKED: the same columns as emspec_batch(out->index), but
+ * what crosses PCIe is the lossless wire image above (~186 B instead of 1,024 B per column on typical audio), ONE IMAGE
+ * PER STREAM, tightly packed into `wire` (host memory, pinned for full speed) in stream order: stream s occupies
+ * wire[offsets[s] .. offsets[s+1]) (offsets: streams + 1 entries, offsets[0] = 0, every image 16-byte aligned).
+ * wire_capacity = streams x emspec_wire_bound(columns, rows) always suffices; EMSPEC_ERR_INVALID_ARG when the images do not
+ * fit.  Runs the three-stage pipeline of emspec_batch (H2D | kernels + pack | D2H on three HIP streams); rows % 4 == 0.
+ * Serves: the renderer-side batched computeColumns when the host keeps or forwards the columns compressed
+ * (north_star: "host code stays in JavaScript/Node calling HIP through a thin C-ABI N-API addon").
+ * emspec_wire_unpack_host: expand one image on the host's own cores (plain C, no device, no engine):
+ * wire -> index_out [columns][rows]; validates the header and every offset (a damaged image is rejected, never
+ * read or written out of range).
+ */
+int emspec_batch_packed(emspec_engine* e, const float* pcm, int32_t streams, int64_t samples_per_stream, int32_t fft_size,
+                        int32_t hop, int32_t reassign, uint8_t* wire, int64_t wire_capacity, int64_t* offsets);
+int emspec_wire_unpack_host(const uint8_t* wire, int64_t wire_bytes, int64_t columns, int32_t rows, uint8_t* index_out);
+
 /* Copy out the tables the kernels use for (n): row edges in bin units
  * (rows+1 floats) and the twiddle table (n/2 complex = n floats, re,im
  * interleaved).  Either pointer may be NULL.  For table-parity tests. */

@@ -185,3 +185,35 @@ def test_display_laws_are_shared_by_every_binding():
         out = json.loads(subprocess.run([node, "-e", js], capture_output=True, text=True, check=True, timeout=60).stdout)
         assert np.array_equal(np.array(out["w"], np.float32), w)
         assert np.array_equal(np.array(out["c"], np.uint8).reshape(256, 4), emspec.make_colormap(0.7))
+
+
+def test_wire_unpack_host_matches_the_numpy_wire_reference():
+    """emspec_wire_unpack_host (plain C in the product library: no device, no engine) expands the images that the numpy
+    restatement of the wire format (oracle/wire_ref.py) packs - random sparse columns, dense columns, empty columns, a row
+    count that is not a multiple of 32 - and rejects damaged images instead of reading or writing out of range."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import wire_ref as W
+    rng = np.random.default_rng(77)
+    for columns, rows, density in ((1, 64, 0.5), (37, 1024, 0.06), (300, 1024, 0.0), (12, 100, 1.0), (129, 256, 0.3)):
+        idx = (rng.integers(1, 256, size=(columns, rows)) * (rng.random((columns, rows)) < density)).astype(np.uint8)
+        img = W.pack(idx)
+        got = emspec.wire_unpack_host(img, columns, rows)
+        assert np.array_equal(got, idx), (columns, rows, density)
+        assert np.array_equal(emspec.wire_unpack_host(np.concatenate([img, np.zeros(40, np.uint8)]), columns, rows), idx)   # slack behind the image
+        for bad in (img[:31], img[:len(img) // 2] if density > 0 else img[:32 + columns * 2]):
+            with pytest.raises(emspec.EmspecError):
+                emspec.wire_unpack_host(bad, columns, rows)
+        with pytest.raises(emspec.EmspecError):
+            emspec.wire_unpack_host(img, columns + 1, rows)
+        wrong = img.copy()
+        wrong[0] ^= 1                                        # magic
+        with pytest.raises(emspec.EmspecError):
+            emspec.wire_unpack_host(wrong, columns, rows)
+    # a mask that claims more cells than the payload holds is caught while expanding
+    idx = np.zeros((2, 64), np.uint8)
+    idx[0, 3] = 9
+    img = W.pack(idx).copy()
+    img[32 + 2 * 4 + 4] = 0xFF                               # column 0's second mask word: eight more cells than the payload has
+    with pytest.raises(emspec.EmspecError):
+        emspec.wire_unpack_host(img, 2, 64)

@@ -1,0 +1,136 @@
+"""-m gpu: the host-buffer entry points (emspec_batch / emspec_batch_packed) - the three-stage pipeline over chunks of
+streams (H2D | kernels | D2H on three HIP streams, three staging sets) must return exactly what the device-resident call
+returns, in both arithmetic modes and with the display post-process, and the packed form's images must expand (on the
+host, emspec_wire_unpack_host) to the same palette indices."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "em-spec_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import emspec  # noqa: E402
+import oracle as O  # noqa: E402
+from emspec import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(a):
+    p = emspec.PinnedArray(a.shape, a.dtype)
+    p.array[...] = a
+    return p
+
+
+def _batch_pinned(e, pcm, n, hop, want=("db", "index")):
+    """emspec_batch with EVERY host buffer page-locked (the condition for the pipelined path); returns copies."""
+    import ctypes as C
+    S, L = pcm.shape
+    Cn = emspec.num_columns(L, n, hop)
+    pin = _pinned(pcm)
+    pdb = emspec.PinnedArray((S, Cn, e.rows), np.float32) if "db" in want else None
+    pix = emspec.PinnedArray((S, Cn, e.rows), np.uint8) if "index" in want else None
+    try:
+        if pdb is not None:
+            pdb.array[...] = -1.0
+        if pix is not None:
+            pix.array[...] = 255
+        out = emspec.Out(pdb.array.ctypes.data if pdb else None, None, pix.array.ctypes.data if pix else None)
+        e._chk(e._lib.emspec_batch(e._h, C.c_void_p(pin.array.ctypes.data), S, L, n, hop, 1, C.byref(out)))
+        return {"db": pdb.array.copy() if pdb else None, "index": pix.array.copy() if pix else None}
+    finally:
+        pin.close()
+        if pdb:
+            pdb.close()
+        if pix:
+            pix.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_pipelined_batch_equals_device_resident_batch(mode):
+    """23 streams from pinned buffers: 12 chunks of two streams through three staging sets (every set is reused three
+    times, the last chunk is short).  EXACT mode: bytes equal to the bit model; FAST mode: palette index equal to the
+    device-resident call's except for its documented +-1 cells, dB within a few ulp of it."""
+    import torch
+    n, hop, S = 4096, 256, 23
+    L = n + hop * 299 + 17
+    pcm = synth.streams(S, L)
+    Cn = emspec.num_columns(L, n, hop)
+    with emspec.Engine(mode=emspec.MODE_EXACT if mode == "exact" else emspec.MODE_FAST) as e:
+        got = _batch_pinned(e, pcm, n, hop)
+        gdb, gix = got["db"], got["index"]
+        x = torch.from_numpy(pcm).cuda()
+        db = torch.empty((S, Cn, e.rows), dtype=torch.float32, device="cuda")
+        ix = torch.empty((S, Cn, e.rows), dtype=torch.uint8, device="cuda")
+        e.batch_device(x, n, hop, True, db=db, index=ix)
+        torch.cuda.synchronize()
+        rdb, rix = db.cpu().numpy(), ix.cpu().numpy()
+    if mode == "exact":
+        assert np.array_equal(gix, rix) and np.array_equal(gdb.view(np.uint32), rdb.view(np.uint32))
+        odb, _, oix, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm[20:], want=("db", "index"))
+        assert np.array_equal(gix[20:], oix) and np.array_equal(gdb[20:].view(np.uint32), odb.view(np.uint32))
+    else:
+        d = np.abs(gix.astype(int) - rix.astype(int))
+        assert d.max() <= 1 and np.mean(d != 0) < 1e-4
+        assert np.max(np.abs(gdb - rdb)) < 1e-3
+
+
+def test_packed_batch_images_expand_to_the_plain_columns():
+    """emspec_batch_packed: one lossless wire image per stream, tightly packed in stream order; every image expands on the
+    host (emspec_wire_unpack_host) to the palette indices emspec_batch returns; the images are a fraction of the raw bytes;
+    a buffer that cannot hold them is refused with a message, nothing is written past it."""
+    n, hop, S = 4096, 256, 11
+    L = n + hop * 399
+    pcm = synth.streams(S, L)
+    Cn = emspec.num_columns(L, n, hop)
+    with emspec.Engine(mode=emspec.MODE_EXACT) as e:
+        ref = e.batch(pcm, n, hop, True, want=("index",))["index"]
+        pin = _pinned(pcm)
+        pw = emspec.PinnedArray((S * emspec.wire_bound(Cn, e.rows),), np.uint8)
+        try:
+            wire, offs = e.batch_packed(pin.array, n, hop, True, wire=pw.array)
+            assert offs[0] == 0 and np.all(np.diff(offs) > 0) and np.all(offs % 16 == 0)
+            assert offs[-1] < 0.5 * ref.size                      # packed: well under the raw bytes on this input
+            for s in range(S):
+                got = emspec.wire_unpack_host(wire[offs[s]:offs[s + 1]], Cn, e.rows)
+                assert np.array_equal(got, ref[s]), s
+            # pageable buffers work too (slower), and so does a single stream
+            w2, o2 = e.batch_packed(pcm[:1], n, hop, True)
+            assert np.array_equal(emspec.wire_unpack_host(w2[:o2[1]], Cn, e.rows), ref[0])
+            small = np.full(int(offs[3]) + 64, 0xAB, np.uint8)
+            with pytest.raises(emspec.EmspecError) as ei:
+                e.batch_packed(pin.array, n, hop, True, wire=small[:int(offs[3])])
+            assert "too small" in str(ei.value) and np.all(small[int(offs[3]):] == 0xAB)
+        finally:
+            pin.close(); pw.close()
+    # the fast mode's images: equal to its own plain columns up to the mode's +-1 cells (two runs of float accumulates)
+    with emspec.Engine() as f:
+        ref = f.batch(pcm[:3], n, hop, True, want=("index",))["index"]
+        wire, offs = f.batch_packed(pcm[:3], n, hop, True)
+        for s in range(3):
+            got = emspec.wire_unpack_host(wire[offs[s]:offs[s + 1]], Cn, f.rows)
+            d = np.abs(got.astype(int) - ref[s].astype(int))
+            assert d.max() <= 1 and np.mean(d != 0) < 1e-4
+
+
+def test_pipelined_batch_with_display_postprocess_and_other_sizes():
+    """The per-engine workspaces of the display post-process and of the N = 16384 EXACT records path are used by one chunk at
+    a time (every kernel runs on the engine's compute stream): pinned batches through the pipeline equal the one-chunk result."""
+    n, hop, S = 1024, 256, 9
+    L = n + hop * 499
+    pcm = synth.streams(S, L)
+    with emspec.Engine() as e:
+        e.set_display(smoothing=0.5, agc_strength=0.7)
+        one = np.concatenate([e.batch(pcm[s:s + 1], n, hop, True, want=("db",))["db"] for s in range(S)])
+        got = _batch_pinned(e, pcm, n, hop, want=("db",))["db"]
+    assert np.max(np.abs(got - one)) < 2e-3
+    n, hop, S = 16384, 512, 5
+    L = n + hop * 59
+    pcm = synth.streams(S, L)
+    with emspec.Engine(mode=emspec.MODE_EXACT) as x:
+        got = _batch_pinned(x, pcm, n, hop)
+    odb, _, oix, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+    assert np.array_equal(got["index"], oix) and np.array_equal(got["db"].view(np.uint32), odb.view(np.uint32))
