@@ -215,6 +215,69 @@ def js_baseline(n, hop, seconds=5.0):
         return None
 
 
+def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
+    """PCIe-inclusive rates of the host-buffer entry points on the headline shape (emspec_batch index out, emspec_batch_packed;
+    pinned buffers from emspec_host_alloc), each with a PCIe roofline whose peak is the hipMemcpy rate measured here on the
+    same buffers.  `value` of the bench line never includes PCIe; these are the figures a host-memory caller sees."""
+    import ctypes as C_
+    import emspec
+    lib = emspec.load()
+    S = int(pcm_dev.shape[0])
+    Cn = emspec.num_columns(L, n, hop)
+    pin = emspec.PinnedArray((S, L), np.float32)
+    pix = emspec.PinnedArray((S, Cn, R), np.uint8)
+    out = {}
+    try:
+        pin.array[...] = pcm_dev.cpu().numpy()
+        hip = C_.CDLL("libamdhip64.so")
+        scratch = torch.empty(pin.array.nbytes, dtype=torch.uint8, device=pcm_dev.device)
+
+        def copy_rate(h2d):
+            best = 0.0
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if h2d:
+                    rc = hip.hipMemcpy(C_.c_void_p(scratch.data_ptr()), C_.c_void_p(pin.array.ctypes.data), C_.c_size_t(pin.array.nbytes), 1)
+                else:
+                    rc = hip.hipMemcpy(C_.c_void_p(pix.array.ctypes.data), C_.c_void_p(scratch.data_ptr()), C_.c_size_t(pix.array.nbytes), 2)
+                assert rc == 0
+                best = max(best, (pin.array.nbytes if h2d else pix.array.nbytes) / (time.perf_counter() - t0) / 1e9)
+            return best
+        h2d, d2h = copy_rate(True), copy_rate(False)
+        del scratch
+
+        def timed(fn):
+            fn()
+            t = []
+            for _ in range(3):
+                t0 = time.perf_counter(); fn(); t.append(time.perf_counter() - t0)
+            return float(np.median(t))
+        o = emspec.Out(None, None, C_.c_void_p(pix.array.ctypes.data))
+        dt = timed(lambda: eng._chk(lib.emspec_batch(eng._h, C_.c_void_p(pin.array.ctypes.data), S, L, n, hop, 1, C_.byref(o))))
+        gbs = pin.array.nbytes / dt / 1e9
+        out[f"host buffers (pinned): {S} streams, FFT {n}, hop {hop}, reassignment ON, uint8 palette index out (emspec_batch)"] = {
+            "columns_per_s": S * Cn / dt, "ms": dt * 1e3,
+            "roofline": {"bound": "pcie", "achieved": gbs, "peak": min(h2d, d2h), "unit": "GB/s", "frac": gbs / min(h2d, d2h),
+                         "note": "4*hop B in and R B out per column, both directions busy at once; peak = the slower of the hipMemcpy "
+                                 "rates measured here on the same pinned buffers (one direction at a time)",
+                         "h2d_GBps": h2d, "d2h_GBps": d2h}}
+        wire = pix.array.reshape(-1)
+        offs = np.zeros(S + 1, np.int64)
+        dt = timed(lambda: eng._chk(lib.emspec_batch_packed(eng._h, C_.c_void_p(pin.array.ctypes.data), S, L, n, hop, 1, C_.c_void_p(wire.ctypes.data),
+                                                            C_.c_int64(wire.size), offs.ctypes.data_as(C_.c_void_p))))
+        gbs = pin.array.nbytes / dt / 1e9
+        out[f"host buffers (pinned): {S} streams, FFT {n}, hop {hop}, reassignment ON, packed wire images out (emspec_batch_packed)"] = {
+            "columns_per_s": S * Cn / dt, "ms": dt * 1e3, "wire_bytes_per_column": float(offs[-1]) / (S * Cn),
+            "roofline": {"bound": "pcie", "achieved": gbs, "peak": h2d, "unit": "GB/s", "frac": gbs / h2d,
+                         "note": "4*hop B in per column (the images going out are ~0.18 of that); peak = the hipMemcpy H2D rate "
+                                 "measured here on the same pinned buffer", "h2d_GBps": h2d, "d2h_GBps": d2h}}
+    finally:
+        pin.close()
+        pix.close()
+    return out
+
+
 class Watchdog:
     """A per-step deadline on a daemon thread: a rank that stops making progress (a peer died inside a collective, a kernel
     never returns) ends its process with exit code 1 - the launcher then stops the job - instead of hanging until the
@@ -829,6 +892,14 @@ def main():
                 xs = _synth.streams(1, 4096 + 256 * 1023)
                 t0 = time.perf_counter(); O.batch_exact(O.make_cfg(4096, 256, True), xs, want=("db", "index"), threads=1); dtx = time.perf_counter() - t0
                 cfgs[xname]["cpu_port_columns_per_s_one_thread"] = 1024 / dtx
+            # ---- the host-buffer entries (what a Node host calls: every byte crosses PCIe): emspec_batch with the uint8 palette
+            # index out, and emspec_batch_packed (the index columns as lossless wire images), from page-locked buffers, on the
+            # three-stage pipeline (H2D | kernels | D2H on three HIP streams).  Their roofline is PCIe: the measured hipMemcpy
+            # rate of the same buffers, one direction.
+            try:
+                cfgs.update(host_buffer_configs(eng, pcm, L, n, hop, R))
+            except Exception as ex:            # never lose the line over the side measurement
+                cfgs["host buffers"] = {"error": repr(ex)}
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
 

@@ -260,6 +260,9 @@ ExactPlanDev exact_plan_dev(const emspec_engine* e, const Plan& p, int hop, int 
     while ((1 << log2n) < p.n) ++log2n;
     d.qscale = std::ldexp(1.0, 52 - (2 * log2n - 4));
     d.pmax = std::ldexp(1.0, 61) / d.qscale;
+    d.pfloor64 = 64.0 * d.pfloor;
+    d.pmax64 = 64.0 * d.pmax;
+    d.qscale64 = d.qscale / 64.0;
     d.e0 = p.h_e0;
     d.eR = p.h_eR;
     d.l2e0 = std::log2((float)p.h_e0);
@@ -267,13 +270,14 @@ ExactPlanDev exact_plan_dev(const emspec_engine* e, const Plan& p, int hop, int 
     return d;
 }
 ExactDbMap exact_db_map(const emspec_engine* e, int n, const ExactPlanDev& pd) {
+    // (oracle/emspec_exact.c: eo_batch_exact states the same operations; every constant is rounded once to binary32)
     ExactDbMap m;
     const double nn = (double)n;
-    m.scale = 32.0 / (3.0 * nn * nn) * (double)e->cfg.gain * (double)e->cfg.gain;
-    m.lo = (double)e->cfg.db_top - (double)e->cfg.db_range;
-    m.inv_range = 1.0 / (double)e->cfg.db_range;
-    m.gate = (double)e->cfg.gate_db;
-    m.inv_q = 1.0 / pd.qscale;
+    const double scale = 32.0 / (3.0 * nn * nn) * (double)e->cfg.gain * (double)e->cfg.gain;
+    m.sc = (float)(scale * (1.0 / pd.qscale));
+    m.lo = (float)((double)e->cfg.db_top - (double)e->cfg.db_range);
+    m.inv_range = (float)(1.0 / (double)e->cfg.db_range);
+    m.gate = e->cfg.gate_db;
     return m;
 }
 

@@ -73,11 +73,14 @@ struct ExactPlanDev {
     double pfloor;       // gate on |X_h|^2
     double pmax;         // upper gate = 2^61 / qscale
     double qscale;       // fixed-point units per unit of |X_h|^2: 2^52 / (N/4)^2, a power of two
+    // the same gates and scale on den = 64 P (exact powers of two away: the branch-free core compares and converts den itself)
+    double pfloor64, pmax64, qscale64;
     // for the branch-free per-bin core of exact_fused.hip.inc (log-spaced rows): the table's ends and the float32 log2 hint
     double e0, eR;       // ebin[0], ebin[rows]
     float l2e0, rscale;  // log2(e0), rows / (log2(eR) - log2(e0))
 };
-struct ExactDbMap { double scale, lo, inv_range, gate, inv_q; };
+// stage "dB + colour" of the EXACT mode: binary32; sc = (float)(scale / qscale): fixed-point sum -> dB argument
+struct ExactDbMap { float sc, lo, inv_range, gate; };
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

@@ -69,7 +69,7 @@ function checkExactAgainstJsOracle(fftSize, hop, frames) {
 /* ABI 2: what the loaded libemspec was built from */
 /* the packed throughput entry: one wire image per stream over PCIe, expanded on the host's own cores */
 function checkPacked() {
-  const eng = em.createEngine({ mode: 1 });          // EXACT: the two calls give the same bytes
+  const eng = em.createEngine({ exact: true });      // EXACT: the two calls give the same bytes
   const fftSize = 4096, hop = 256, frames = 60, S = 5, L = fftSize + hop * (frames - 1);
   const R = eng.rows;
   const pcm = new Float32Array(em.allocPinned(S * L * 4));

@@ -216,32 +216,30 @@ int eo_frames_exact(const eo_cfg* c, const float* pcm, int64_t L, int64_t frame0
     return 0;
 }
 
-/* stage "dB + colour", exact mode: 10 log10 through a SPECIFIED binary64 evaluation (no libm call, so the GPU and
- * the CPU produce the same bits): x = m 2^e with m in (sqrt(1/2), sqrt 2], s = (m-1)/(m+1),
- * log2 m = (2/ln 2) s (1 + z/3 + ... + z^10/21), z = s^2 (|s| <= 0.1716: truncation < 1e-18). */
-double eo_exact_db(double x) {
-    union { double d; uint64_t u; } v;
-    v.d = x;
-    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
-    v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
-    double m = v.d;
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
-    double s = (m - 1.0) / (m + 1.0);
-    double z = s * s;
-    double pz = 1.0 / 21.0;
-    pz = fma(pz, z, 1.0 / 19.0);
-    pz = fma(pz, z, 1.0 / 17.0);
-    pz = fma(pz, z, 1.0 / 15.0);
-    pz = fma(pz, z, 1.0 / 13.0);
-    pz = fma(pz, z, 1.0 / 11.0);
-    pz = fma(pz, z, 1.0 / 9.0);
-    pz = fma(pz, z, 1.0 / 7.0);
-    pz = fma(pz, z, 1.0 / 5.0);
-    pz = fma(pz, z, 1.0 / 3.0);
-    pz = fma(pz, z, 1.0);
-    double l2 = (s * pz) * 2.8853900817779268; /* 2 / ln 2 */
-    return ((double)e + l2) * 3.0102999566398120; /* 10 log10(2) */
+/* stage "dB + colour", exact mode: 10 log10 through a SPECIFIED binary32 evaluation (no libm call; IEEE operations in this
+ * order, fmaf where written, so the GPU and the CPU produce the same bits): x = m 2^e with m in (sqrt(1/2), sqrt 2],
+ * s = (m-1)/(m+1), log2 m = (2/ln 2) s (1 + z/3 + z^2/5 + z^3/7 + z^4/9), z = s^2 (|s| <= 0.1716: truncation 2e-9, below
+ * binary32's resolution).  Round 5: binary32 instead of binary64 - the outputs are a float32 dB and a palette byte, and on
+ * MI355X a binary64 vector instruction costs four binary32 ones; the indices, the energies and their sums stay binary64 /
+ * int64.  The cell's energy enters as (float)sum (int64 -> binary32, one rounding). */
+float eo_exact_db32(float x) {
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    int e = (int)((v.u >> 23) & 0xff) - 127;
+    v.u = (v.u & 0x007fffffu) | 0x3f800000u;
+    float m = v.f;
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float pz = 1.0f / 9.0f;
+    pz = fmaf(pz, z, 1.0f / 7.0f);
+    pz = fmaf(pz, z, 1.0f / 5.0f);
+    pz = fmaf(pz, z, 1.0f / 3.0f);
+    pz = fmaf(pz, z, 1.0f);
+    float l2 = (s * pz) * 2.88539004f; /* 2 / ln 2 */
+    return ((float)e + l2) * 3.01029992f; /* 10 log10(2) */
 }
+double eo_exact_db(double x) { return (double)eo_exact_db32((float)x); }
 
 /* stage "Scatter" in fixed point + "dB + colour".  hist (optional): the int64 sums [S][C][R]. */
 int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, const uint8_t* lut, float* db,
@@ -254,8 +252,10 @@ int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, cons
     const int R = c->rows, K = p.K;
     const double nn = (double)c->n;
     const double scale = 32.0 / (3.0 * nn * nn) * (double)c->gain * (double)c->gain;
-    const double lo = (double)c->db_top - (double)c->db_range, inv_range = 1.0 / (double)c->db_range;
-    const double gate = (double)c->gate_db, inv_q = 1.0 / p.qscale;
+    /* the stage's constants, each rounded once to binary32 (emspec_api.cpp: exact_db_map states the same operations) */
+    const float sc = (float)(scale * (1.0 / p.qscale));
+    const float lo = (float)((double)c->db_top - (double)c->db_range), inv_range = (float)(1.0 / (double)c->db_range);
+    const float gate = c->gate_db;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
@@ -274,13 +274,12 @@ int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, cons
         }
         size_t base = (size_t)s * C * R;
         for (size_t i = 0; i < (size_t)C * R; ++i) {
-            double E = (double)hist[i] * inv_q;
-            double d = eo_exact_db(fma(E, scale, 1e-20));
-            double v = (d - lo) * inv_range;
-            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-            if (d < gate) v = 0.0;
-            int ix = (int)(v * 255.0 + 0.5);
-            if (db) db[base + i] = (float)d;
+            float d = eo_exact_db32(fmaf((float)hist[i], sc, 1e-20f));
+            float v = (d - lo) * inv_range;
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            if (d < gate) v = 0.0f;
+            int ix = (int)(v * 255.0f + 0.5f);
+            if (db) db[base + i] = d;
             if (index) index[base + i] = (uint8_t)ix;
             if (rgba) memcpy(rgba + 4 * (base + i), lut + 4 * ix, 4);
             if (hist_out) hist_out[base + i] = hist[i];

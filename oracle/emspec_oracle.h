@@ -77,7 +77,8 @@ int eo_frames_exact(const eo_cfg* c, const float* pcm, int64_t L, int64_t frame0
                     double* power, int32_t* col, int32_t* row, int64_t* q);
 int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, const uint8_t* lut, float* db,
                    uint8_t* rgba, uint8_t* index, int64_t* hist, int32_t threads);
-double eo_exact_db(double x);
+double eo_exact_db(double x);   /* = (double)eo_exact_db32((float)x) */
+float eo_exact_db32(float x);
 
 /* emspec_cpu_fast.c: the same pipeline written for speed on a CPU (Stockham radix-4 FFT, ring histogram, vectorised
  * dB), for bench.py's cpu_baseline leg.  Not bit-identical to the bit model; checked against it at the test tolerance. */

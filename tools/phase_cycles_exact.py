@@ -36,8 +36,13 @@ torch.cuda.synchronize()
 cyc = np.zeros((groups.value, waves.value, 8), np.uint64)
 for _ in range(2):   # second run: clock warm
     assert f(eng._h, pcm.data_ptr(), S, L, n, hop, 1, db.data_ptr(), idx.data_ptr(), cyc.ctypes.data, C.byref(groups), C.byref(waves)) == 0
-names = ["F1 scatter + take column", "F2 park, write A", "F3 passes B C D", "F4 spectrum reads", "F5 unpark",
-         "F  sync waits (5)", "V  work (bins, dB, pass A)", "V  barrier waits"]
+# exact_fused4096_lr_kernel (round 5: no parking; EMSPEC_EXACT_PARKED=1 stamps round 4's kernel instead)
+if os.environ.get("EMSPEC_EXACT_PARKED") == "1":
+    names = ["F1 scatter + take column", "F2 park, write A", "F3 passes B C D", "F4 spectrum reads", "F5 unpark",
+             "F  sync waits (5)", "V  work (bins, dB, pass A)", "V  barrier waits"]
+else:
+    names = ["F1 take column + scatter", "F1 write A", "F2 passes B C D (+ dB)", "F3 spectrum reads", "-",
+             "F  sync waits (2) + barrier", "V  work (bins, pass A)", "V  barrier wait"]
 ticks = (cyc[:, :, 7] >> np.uint64(32)).astype(np.float64)          # 100 MHz
 cyc[:, :, 7] &= np.uint64(0xFFFFFFFF)
 c = cyc.astype(np.float64)
