@@ -455,7 +455,7 @@ def main():
         def dump():
             assert lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(), cl_.data_ptr(),
                                                  rw_.data_ptr(), C_.c_void_p(cur.cuda_stream)) == 0
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(max(args.warmup, 50)):      # a 0.7 ms kernel: >= 50 untimed launches let the clock settle on it (boxes differ by 20 % cold)
             dump()
         torch.cuda.synchronize(dev)
         ms = time_launches(dump, cur, args.steps)
@@ -918,7 +918,7 @@ def main():
                 rcode = lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(),
                                                       cl_.data_ptr(), rw_.data_ptr(), C_.c_void_p(cur.cuda_stream))
                 assert rcode == 0
-            for _ in range(20):        # a 0.7 ms kernel: let the clock settle on it before timing (boxes differ by 20 % cold)
+            for _ in range(50):        # a 0.7 ms kernel: let the clock settle on it before timing (boxes differ by 20 % cold)
                 dump()
             dms = time_launches(dump, cur, 40)
             bpc = 4 * hop + 12 * K

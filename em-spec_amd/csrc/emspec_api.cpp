@@ -845,7 +845,11 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s) + al(wire_s);
     // chunks: about sixteen per batch (pipeline fill and drain stay small beside the steady state), bounded by 1 GiB of
     // staging per set; a chunk of a few streams still fills the chip (segments are cut per launch)
-    int chunk = (S + 15) / 16;
+    int target = 16;
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) target = v; }   // A/B aid
+#endif
+    int chunk = (S + target - 1) / target;
     const int fit = (int)(((size_t)1 << 30) / per_stream);
     chunk = chunk > fit ? fit : chunk;
     chunk = chunk < 1 ? 1 : chunk;

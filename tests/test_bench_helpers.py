@@ -65,6 +65,44 @@ def test_committed_profiles_are_complete():
                           f"tools/profile_workload.sh + tools/profile_json.py are re-run")
 
 
+def test_profile_durations_do_not_exceed_the_bench_lines():
+    """a kernel cannot take longer than the measurement that contains it.  For every workload of the newest
+    committed bench line (profiles/r*_bench_n1.json) whose committed rocprofv3 summary was taken on the SAME sources, the
+    kernel-trace median must not exceed the line's HIP-event kernel time by more than 2 % (different boxes, same kernel)."""
+    import glob
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+    assert lines
+    tag = os.path.basename(lines[-1]).split("_")[0]
+    if tag < "r05":
+        import pytest
+        pytest.skip("the rule holds from round 5 on (round 4's parity-dump profile was taken on an unsettled clock)")
+    b = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    sha = b["config"]["sources_sha"]
+    pairs = {"batch64": b["roofline"]["kernel_ms"]}
+    cfgs = b.get("configs") or {}
+    for name, c in cfgs.items():
+        if name.startswith("configs[4]:"):
+            pairs["n16384"] = c["kernel_ms"]
+        if name.startswith("EXACT mode, configs[2]"):
+            pairs["exact64"] = c["kernel_ms"]
+        if name.startswith("EXACT mode, configs[4]"):
+            pairs["exact_n16384"] = c["kernel_ms"]
+    if b.get("roofline_parity_dump"):
+        pairs["paritydump"] = b["roofline_parity_dump"]["kernel_ms"]
+    checked = 0
+    for wl, ms in pairs.items():
+        f = os.path.join(ROOT, "profiles", f"{tag}_{wl}.json")
+        if not os.path.exists(f):
+            continue
+        p = json.load(open(f))
+        if p.get("sources_sha") != sha:
+            continue                      # taken on other kernels than the line: not comparable
+        assert p["rocprof_median_ms"] <= 1.02 * ms, (wl, p["rocprof_median_ms"], ms)
+        checked += 1
+    if tag >= "r05":
+        assert checked >= 3, (tag, checked, sorted(pairs))
+
+
 def test_host_cores_respects_quota_and_smt():
     use, phys, logical = bench.host_cores()
     assert 1 <= use <= phys <= logical

@@ -25,7 +25,8 @@ res = {"streams": S, "columns": S * Cn}
 pin = emspec.PinnedArray((S, L), np.float32)
 pin.array[...] = synth_device(S, L, 0, dev).cpu().numpy()
 pix = emspec.PinnedArray((S, Cn, 1024), np.uint8)
-lib = emspec.load()
+DIAG = bool(os.environ.get("EMSPEC_PIPE_CHUNKS"))      # the chunk-count switch lives in the diagnostic build
+lib = emspec.load(diag=DIAG)
 hip = C.CDLL("libamdhip64.so")
 
 
@@ -62,7 +63,7 @@ def timed(fn, reps=3):
 
 
 for mode, name in ((emspec.MODE_FAST, "fast"), (emspec.MODE_EXACT, "exact")):
-    with emspec.Engine(mode=mode) as e:
+    with emspec.Engine(mode=mode, diag=DIAG) as e:
         o = emspec.Out(None, None, C.c_void_p(pix.array.ctypes.data))
 
         def run_idx():
@@ -90,7 +91,7 @@ for mode, name in ((emspec.MODE_FAST, "fast"), (emspec.MODE_EXACT, "exact")):
             res["host_unpack_columns_per_s_one_core"] = Cn / du
             print(f"emspec_wire_unpack_host: {Cn / du:.3e} columns/s on one core", flush=True)
     if mode == emspec.MODE_FAST and S <= 64:
-        with emspec.Engine(mode=mode) as e:
+        with emspec.Engine(mode=mode, diag=DIAG) as e:
             pdb = emspec.PinnedArray((min(S, 16), Cn, 1024), np.float32)
             Sd = min(S, 16)
             o = emspec.Out(C.c_void_p(pdb.array.ctypes.data), None, None)

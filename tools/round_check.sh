@@ -1,21 +1,26 @@
 #!/bin/bash
 # Everything a round's numbers come from, on one MI355X box (run from the repo root through gpurun):
-#   gpurun --timeout 1200 -- 'bash tools/round_check.sh r02'
+#   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 a'   then   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 b'
+# (two calls since round 5: five profile sets + the suite no longer fit one 20-minute call; `a` = suite + the float32
+# workloads, `b` = the EXACT workloads + the stamped builds and rate tools)
 # 1. the GPU test suite; 2. rocprofv3 profiles of the two bench workloads (tools/profile_workload.sh: kernel trace +
 # separate PMC passes); 3. stamped-build phase cycles and the in-kernel clock; 4. gather cost; 5. host-API rates.
 # Afterwards, HERE:  python tools/profile_json.py gpurun_out/<tag>_batch64 <tag> batch64 1047616
 #                    python tools/profile_json.py gpurun_out/<tag>_n16384 <tag> n16384 522304
-#                    python tools/profile_json.py gpurun_out/<tag>_paritydump <tag> paritydump 65296
+#                    python tools/profile_json.py gpurun_out/<tag>_paritydump <tag> paritydump 65296 --last 20
 #                    python tools/profile_json.py gpurun_out/<tag>_exact64 <tag> exact64 1047616
+#                    python tools/profile_json.py gpurun_out/<tag>_exact_n16384 <tag> exact_n16384 522304 --all-kernels
 #                    cp gpurun_out/<tag>_*.txt profiles/   and commit;
 # then a second call for the bench lines, which quote the counters only while profiles/<tag>_*.json match the kernels:
 #   gpurun -- 'python bench.py > gpurun_out/<tag>_bench_n1.json; python bench.py --gather loopback --no-cpu-baseline
 #              --no-configs > gpurun_out/<tag>_bench_loopback.json'
 set -e
 tag=${1:-r02}
+part=${2:-ab}
 export TMPDIR=/tmp
 R=$(pwd)
 mkdir -p gpurun_out
+if [[ $part == *a* ]]; then
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -40 gpurun_out/gpu_tests.log; exit 1; }
 tail -2 gpurun_out/gpu_tests.log
 bash tools/profile_workload.sh ${tag}_batch64 --no-configs > gpurun_out/prof_batch64.log 2>&1
@@ -24,8 +29,12 @@ bash tools/profile_workload.sh ${tag}_n16384 --workload n16384 > gpurun_out/prof
 echo "n16384 profiled"
 bash tools/profile_workload.sh ${tag}_paritydump --workload paritydump --steps 20 > gpurun_out/prof_paritydump.log 2>&1
 echo "paritydump profiled"
+fi
+if [[ $part == *b* ]]; then
 bash tools/profile_workload.sh ${tag}_exact64 --mode exact --no-configs > gpurun_out/prof_exact64.log 2>&1
 echo "exact64 profiled"
+bash tools/profile_workload.sh ${tag}_exact_n16384 --mode exact --workload n16384 > gpurun_out/prof_exact_n16384.log 2>&1
+echo "exact_n16384 profiled"
 cd "$R"
 timeout -k 10 200 python tools/phase_cycles.py 64 waves > gpurun_out/${tag}_batch64_phase_cycles.txt 2>&1
 timeout -k 10 200 python tools/phase_cycles_n16384.py > gpurun_out/${tag}_n16384_phase_cycles.txt 2>&1 || true
@@ -33,4 +42,6 @@ timeout -k 10 200 python tools/phase_cycles_exact.py 64 waves > gpurun_out/${tag
 timeout -k 10 200 python tools/kernel_clock.py > gpurun_out/${tag}_kernel_clock.txt 2>&1 || true
 timeout -k 10 200 python tools/gather_cost.py > gpurun_out/${tag}_gather_cost.txt 2>&1 || true
 timeout -k 10 300 python tools/host_rates.py > gpurun_out/${tag}_host_api_rate.txt 2>&1 || true
-echo "round check written under gpurun_out/"
+timeout -k 10 300 python tools/host_pipeline_rates.py > gpurun_out/${tag}_host_pipeline_rate.txt 2>&1 || true
+fi
+echo "round check ($part) written under gpurun_out/"
