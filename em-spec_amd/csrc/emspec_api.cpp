@@ -620,6 +620,20 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     int chunk = 1;
     if ((rc = grow_record_workspace(e, q_per_stream + key_per_stream, 256, (size_t)4 << 30, S, &chunk))) return rc;
     const size_t col_cells = (size_t)C * e->cfg.rows;
+    // the scatter's low-row scratch (exact.hip.inc: a ring too large for LDS is walked with its sparse low rows in global
+    // memory); cleared once per batch - the kernel leaves it zero, this only guards against a launch that was cut short
+    const float* ebin_host = p.h_ebin.data();
+    const size_t low_need = exact_scatter_scratch_bytes(n, pd, chunk, C, ebin_host);
+    if (low_need) {
+        if (low_need > e->xlow_bytes) {
+            if (e->xlow_used) HIPCHK(e, hipEventSynchronize(e->xlow_event));
+            if ((rc = grow(e, (void**)&e->d_xlow, &e->xlow_bytes, low_need))) return rc;
+        }
+        if (!e->xlow_event) HIPCHK(e, hipEventCreateWithFlags(&e->xlow_event, hipEventDisableTiming));
+        if (e->xlow_used) HIPCHK(e, hipStreamWaitEvent(st, e->xlow_event, 0));
+        e->xlow_used = true;
+        HIPCHK(e, hipMemsetAsync(e->d_xlow, 0, low_need, st));
+    }
     for (int s0 = 0; s0 < S; s0 += chunk) {
         const int sc = (S - s0 < chunk) ? S - s0 : chunk;
         ExactSinks sk;
@@ -628,8 +642,10 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
         HIPCHK(e, launch_exact_frames(n, pd, pcm + (size_t)s0 * L, L, sc, 0, C, sk, st));
         HIPCHK(e, launch_exact_tile_scatter(sk.rec_q, sk.rec_key, n, pd, m, e->d_lut, sc, C, db ? db + s0 * col_cells : nullptr,
                                             rgba ? rgba + 4 * s0 * col_cells : nullptr,
-                                            index ? index + s0 * col_cells : nullptr, st));
+                                            index ? index + s0 * col_cells : nullptr, st, low_need ? ebin_host : nullptr,
+                                            low_need ? e->d_xlow : nullptr, low_need ? e->xlow_bytes : 0));
     }
+    if (low_need) HIPCHK(e, hipEventRecord(e->xlow_event, st));
     return EMSPEC_OK;
 }
 

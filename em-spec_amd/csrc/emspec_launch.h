@@ -52,9 +52,14 @@ struct ExactSinks {
 hipError_t launch_exact_frames(int n, const ExactPlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
                                int64_t nframes, const ExactSinks& sinks, hipStream_t st);
 int exact_record_stride(int n);
+// (ebin_f32 / low / low_bytes: the plan's float32 edge table on the host and a zeroed u64 scratch of
+// exact_scatter_scratch_bytes - with them a ring that does not fit LDS is walked with its sparse low rows in that scratch,
+// every record read once; without them, or on an axis with > 6 % of the bins down there: 16-column tiles, records read 3x)
+size_t exact_scatter_scratch_bytes(int n, const ExactPlanDev& pl, int S, int64_t C, const float* ebin_f32);
 hipError_t launch_exact_tile_scatter(const long long* rec_q, const uint32_t* rec_key, int n, const ExactPlanDev& pl,
                                      const ExactDbMap& m, const uint8_t* lut, int S, int64_t C, float* db, uint8_t* rgba,
-                                     uint8_t* index, hipStream_t st);
+                                     uint8_t* index, hipStream_t st, const float* ebin_f32 = nullptr,
+                                     unsigned long long* low = nullptr, size_t low_bytes = 0);
 // EXACT mode, one kernel (exact_fused.hip.inc): N = 4096 at every hop whose u64 column ring fits in LDS
 bool exact_fused_supported(int n, const ExactPlanDev& pl);
 hipError_t launch_exact_fused(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
