@@ -223,6 +223,35 @@ def test_exact_custom_axis_and_settings(xengine, n, hop, frames):
             O.set_custom_edges_hz(None)
 
 
+@pytest.mark.parametrize("n,hop,frames,S", [(4096, 256, 150, 3), (4096, 512, 90, 2), (16384, 512, 60, 2)])
+def test_exact_axes_the_row_split_does_not_serve(n, hop, frames, S):
+    """Round 5 keeps the ring's sparse low rows in global memory (fused kernel at N = 4096, walking scatter elsewhere) when at
+    most 6 % of the bins fall there.  A LINEAR frequency axis puts 43 % of the bins below that row: the fused kernel with the
+    parked ring (round 4's) / the 16-column tile scatter serve it instead - same bytes as the bit model; and on the default
+    axis the diagnostic switch EMSPEC_EXACT_PARKED=1 runs the parked kernel beside the row-split one: identical bytes."""
+    import os
+    pcm = _pcm(n, hop, frames, S=S)
+    edges = np.linspace(40.0, 23000.0, 1025).astype(np.float32)
+    with emspec.Engine(mode=emspec.MODE_EXACT) as e:
+        e.set_row_edges_hz(edges)
+        O.set_custom_edges_hz(edges)
+        try:
+            out = e.batch(pcm, n, hop, True, want=("db", "index"))
+            odb, _, oidx, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
+        finally:
+            O.set_custom_edges_hz(None)
+    assert np.array_equal(out["index"], oidx) and np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32))
+    if n == 4096:
+        with emspec.Engine(mode=emspec.MODE_EXACT, diag=True) as d:
+            a = d.batch(pcm, n, hop, True, want=("db", "index"))
+            os.environ["EMSPEC_EXACT_PARKED"] = "1"
+            try:
+                b = d.batch(pcm, n, hop, True, want=("db", "index"))
+            finally:
+                os.environ.pop("EMSPEC_EXACT_PARKED", None)
+        assert np.array_equal(a["index"], b["index"]) and np.array_equal(a["db"].view(np.uint32), b["db"].view(np.uint32))
+
+
 def test_exact_batch_from_pinned_buffers(xengine):
     """Host-buffer batch from page-locked memory (the fast mode pipelines stream chunks on two HIP streams there; the
     exact mode has one record workspace per engine and must not): > 96 MB of staging, bytes equal to the bit model."""
