@@ -245,6 +245,22 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
                 best = max(best, (pin.array.nbytes if h2d else pix.array.nbytes) / (time.perf_counter() - t0) / 1e9)
             return best
         h2d, d2h = copy_rate(True), copy_rate(False)
+
+        def duplex_rate():
+            """both directions at once (two HIP streams, 1 GB each way): what PCIe gives a pipeline whose copies overlap"""
+            other = torch.empty(pix.array.nbytes, dtype=torch.uint8, device=pcm_dev.device)
+            scratch = torch.empty(pin.array.nbytes, dtype=torch.uint8, device=pcm_dev.device)
+            s1, s2 = torch.cuda.Stream(device=pcm_dev.device), torch.cuda.Stream(device=pcm_dev.device)
+            best = 0.0
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r1 = hip.hipMemcpyAsync(C_.c_void_p(scratch.data_ptr()), C_.c_void_p(pin.array.ctypes.data), C_.c_size_t(pin.array.nbytes), 1, C_.c_void_p(s1.cuda_stream))
+                r2 = hip.hipMemcpyAsync(C_.c_void_p(pix.array.ctypes.data), C_.c_void_p(other.data_ptr()), C_.c_size_t(pix.array.nbytes), 2, C_.c_void_p(s2.cuda_stream))
+                assert r1 == 0 and r2 == 0
+                torch.cuda.synchronize()
+                best = max(best, min(pin.array.nbytes, pix.array.nbytes) / (time.perf_counter() - t0) / 1e9)
+            return best
         del scratch
 
         def timed(fn):
@@ -256,11 +272,13 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
         o = emspec.Out(None, None, C_.c_void_p(pix.array.ctypes.data))
         dt = timed(lambda: eng._chk(lib.emspec_batch(eng._h, C_.c_void_p(pin.array.ctypes.data), S, L, n, hop, 1, C_.byref(o))))
         gbs = pin.array.nbytes / dt / 1e9
-        out[f"host buffers (pinned): {S} streams, FFT {n}, hop {hop}, reassignment ON, uint8 palette index out (emspec_batch)"] = {
+        idx_name = f"host buffers (pinned): {S} streams, FFT {n}, hop {hop}, reassignment ON, uint8 palette index out (emspec_batch)"
+        out[idx_name] = {
             "columns_per_s": S * Cn / dt, "ms": dt * 1e3,
             "roofline": {"bound": "pcie", "achieved": gbs, "peak": min(h2d, d2h), "unit": "GB/s", "frac": gbs / min(h2d, d2h),
                          "note": "4*hop B in and R B out per column, both directions busy at once; peak = the slower of the hipMemcpy "
-                                 "rates measured here on the same pinned buffers (one direction at a time)",
+                                 "rates measured here on the same pinned buffers, one direction at a time; duplex_GBps = what each "
+                                 "direction reaches when two plain hipMemcpyAsync run against each other (frac_of_duplex: against that)",
                          "h2d_GBps": h2d, "d2h_GBps": d2h}}
         wire = pix.array.reshape(-1)
         offs = np.zeros(S + 1, np.int64)
@@ -272,6 +290,10 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
             "roofline": {"bound": "pcie", "achieved": gbs, "peak": h2d, "unit": "GB/s", "frac": gbs / h2d,
                          "note": "4*hop B in per column (the images going out are ~0.18 of that); peak = the hipMemcpy H2D rate "
                                  "measured here on the same pinned buffer", "h2d_GBps": h2d, "d2h_GBps": d2h}}
+        # (last: the test makes two more HIP streams, and which copy engine a stream's transfers use follows from creation order)
+        duplex = duplex_rate()
+        rf = out[idx_name]["roofline"]
+        rf["duplex_GBps"], rf["frac_of_duplex"] = duplex, rf["achieved"] / duplex
     finally:
         pin.close()
         pix.close()

@@ -342,6 +342,11 @@ int emspec_create(const emspec_config* cfg, emspec_engine** out) {
     do {
         if (hipSetDevice(e->device) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipSetDevice failed"); break; }
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipStreamCreate failed"); break; }
+        // the copy streams of the host-buffer pipeline, created with the engine: which copy engine a HIP stream's transfers run on
+        // follows from the order streams are made in, and two that are made late in a process full of other streams can land on
+        // ONE engine - H2D and D2H then take turns (measured: index out 3.4e7 instead of 4.4e7 columns/s)
+        if (hipStreamCreateWithFlags(&e->stream_in, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&e->stream_out, hipStreamNonBlocking) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipStreamCreate failed"); break; }
         if (hipMalloc(&e->d_lut, 1024) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_OUT_OF_MEMORY, "hipMalloc(lut) failed"); break; }
         uint8_t lut[1024];
         default_lut(lut);
@@ -994,19 +999,28 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     const size_t in_s = (size_t)L * sizeof(float);
     const size_t db_s = out->db ? col_cells * 4 : 0, rgba_s = out->rgba ? col_cells * 4 : 0, idx_s = out->index ? col_cells : 0;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, (size_t)S * (al(in_s) + al(db_s) + al(rgba_s) + al(idx_s)) + 1024))) return rc;
-    char* base = e->d_stage;
-    float* d_pcm = (float*)base; base += al(in_s) * S;
-    float* d_db = db_s ? (float*)base : nullptr; base += al(db_s) * S;
-    uint8_t* d_rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * S;
-    uint8_t* d_idx = idx_s ? (uint8_t*)base : nullptr;
+    // one stream, chunks of streams one after the other so that the staging stays bounded (4 GiB) whatever S is
+    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s);
+    int chunk = (int)(((size_t)4 << 30) / per_stream);
+    chunk = chunk < 1 ? 1 : (chunk > S ? S : chunk);
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, (size_t)chunk * per_stream + 1024))) return rc;
     hipStream_t st = e->stream;
-    hipError_t herr = hipMemcpyAsync(d_pcm, pcm, in_s * S, hipMemcpyHostToDevice, st);
-    if (herr == hipSuccess) {
-        rc = emspec_batch_device(e, d_pcm, S, L, n, hop, reassign, d_db, d_rgba, d_idx, st);
-        if (rc == EMSPEC_OK && db_s) herr = hipMemcpyAsync(out->db, d_db, db_s * S, hipMemcpyDeviceToHost, st);
-        if (rc == EMSPEC_OK && herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba, d_rgba, rgba_s * S, hipMemcpyDeviceToHost, st);
-        if (rc == EMSPEC_OK && herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index, d_idx, idx_s * S, hipMemcpyDeviceToHost, st);
+    hipError_t herr = hipSuccess;
+    for (int s0 = 0; s0 < S && rc == EMSPEC_OK && herr == hipSuccess; s0 += chunk) {
+        const int sc = (S - s0 < chunk) ? S - s0 : chunk;
+        char* base = e->d_stage;
+        float* d_pcm = (float*)base; base += al(in_s) * chunk;
+        float* d_db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
+        uint8_t* d_rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
+        uint8_t* d_idx = idx_s ? (uint8_t*)base : nullptr;
+        herr = hipMemcpyAsync(d_pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, st);
+        if (herr != hipSuccess) break;
+        rc = emspec_batch_device(e, d_pcm, sc, L, n, hop, reassign, d_db, d_rgba, d_idx, st);
+        if (rc != EMSPEC_OK) break;
+        if (db_s) herr = hipMemcpyAsync(out->db + (size_t)s0 * col_cells, d_db, db_s * sc, hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba + 4 * (size_t)s0 * col_cells, d_rgba, rgba_s * sc, hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index + (size_t)s0 * col_cells, d_idx, idx_s * sc, hipMemcpyDeviceToHost, st);
+        if (herr == hipSuccess && s0 + chunk < S) herr = hipStreamSynchronize(st);   // the next chunk reuses the staging
     }
     const hipError_t s1 = hipStreamSynchronize(st);
     if (rc != EMSPEC_OK) return rc;

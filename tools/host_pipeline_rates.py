@@ -52,6 +52,7 @@ res["d2h_GBps"] = copy_rate(nb, False)
 print(f"hipMemcpy, pinned, {nb / 1e6:.0f} MB: H2D {res['h2d_GBps']:.1f} GB/s, D2H {res['d2h_GBps']:.1f} GB/s", flush=True)
 
 
+
 def timed(fn, reps=3):
     fn()
     t = []
@@ -102,4 +103,18 @@ for mode, name in ((emspec.MODE_FAST, "fast"), (emspec.MODE_EXACT, "exact")):
             res["fast_db_out_columns_per_s"] = Sd * Cn / dt
             print(f"emspec_batch fast  pinned, float32 dB out ({Sd} streams): {Sd * Cn / dt:.3e} columns/s ({dt * 1e3:.1f} ms; {pdb.array.nbytes / dt / 1e9:.1f} GB/s out)", flush=True)
             pdb.close()
+# both directions at once (two streams): the ceiling of a pipeline whose copies overlap
+da, db_ = torch.empty(nb, dtype=torch.uint8, device=dev), torch.empty(nb, dtype=torch.uint8, device=dev)
+s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+best = 0.0
+for _ in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert hip.hipMemcpyAsync(C.c_void_p(da.data_ptr()), C.c_void_p(pin.array.ctypes.data), C.c_size_t(nb), 1, C.c_void_p(s1.cuda_stream)) == 0
+    assert hip.hipMemcpyAsync(C.c_void_p(pix.array.ctypes.data), C.c_void_p(db_.data_ptr()), C.c_size_t(nb), 2, C.c_void_p(s2.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    best = max(best, nb / (time.perf_counter() - t0) / 1e9)
+res["duplex_GBps"] = best
+print(f"hipMemcpyAsync both ways at once, {nb / 1e6:.0f} MB each: {best:.1f} GB/s per direction", flush=True)
+del da, db_
 print(json.dumps(res))
