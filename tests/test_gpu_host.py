@@ -134,3 +134,17 @@ def test_pipelined_batch_with_display_postprocess_and_other_sizes():
         got = _batch_pinned(x, pcm, n, hop)
     odb, _, oix, _ = O.batch_exact(O.make_cfg(n, hop, True), pcm, want=("db", "index"))
     assert np.array_equal(got["index"], oix) and np.array_equal(got["db"].view(np.uint32), odb.view(np.uint32))
+
+
+@pytest.mark.parametrize("rows,n,hop", [(68, 1024, 256), (100, 2048, 128), (512, 4096, 512)])
+def test_packed_batch_other_row_counts_and_sizes(rows, n, hop):
+    """The wire image's generic form (rows a multiple of 4, not of 32) and other FFT sizes through emspec_batch_packed: every
+    stream's image expands on the host to the columns emspec_batch returns (EXACT mode: the same bytes)."""
+    S, frames = 7, 120
+    L = n + hop * (frames - 1) + 5
+    pcm = synth.streams(S, L)
+    with emspec.Engine(mode=emspec.MODE_EXACT, rows=rows) as e:
+        ref = e.batch(pcm, n, hop, True, want=("index",))["index"]
+        wire, offs = e.batch_packed(pcm, n, hop, True)
+        for s in range(S):
+            assert np.array_equal(emspec.wire_unpack_host(wire[offs[s]:offs[s + 1]], frames, rows), ref[s]), (rows, s)
