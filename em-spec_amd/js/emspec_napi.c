@@ -477,6 +477,92 @@ static napi_value BatchAsync(napi_env env, napi_callback_info info) {
     return promise;
 }
 
+/* batchPackedAsync(handle, pcm, S, L, fftSize, hop, reassign, wire, offsets:Float64Array(S+1)) -> Promise<columns>: batchPacked on the
+ * libuv thread pool.  The typed arrays are kept alive by references; the caller touches neither them nor the engine before
+ * the promise settles. */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[3];
+    emspec_engine* e;
+    const float* pcm;
+    uint8_t* wire;
+    int64_t wire_len;
+    double* offs;
+    int64_t* o64;
+    int32_t S, n, hop, reassign;
+    int64_t L, C;
+    int rc;
+    char msg[256];
+} packed_job;
+
+static void packed_execute(napi_env env, void* data) {
+    (void)env;
+    packed_job* j = (packed_job*)data;
+    j->rc = emspec_batch_packed(j->e, j->pcm, j->S, j->L, j->n, j->hop, j->reassign, j->wire, j->wire_len, j->o64);
+    if (j->rc != EMSPEC_OK) { strncpy(j->msg, emspec_last_error(j->e), sizeof(j->msg) - 1); j->msg[sizeof(j->msg) - 1] = 0; }
+}
+
+static void packed_complete(napi_env env, napi_status status, void* data) {
+    packed_job* j = (packed_job*)data;
+    if (status == napi_ok && j->rc == EMSPEC_OK) for (int32_t i = 0; i <= j->S; ++i) j->offs[i] = (double)j->o64[i];   /* (the array is still referenced) */
+    for (int i = 0; i < 3; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    if (status == napi_ok && j->rc == EMSPEC_OK) {
+        napi_value v; napi_create_int64(env, j->C, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value code, msg, err;
+        napi_create_string_utf8(env, status == napi_ok ? status_name(j->rc) : "EMSPEC_NAPI", NAPI_AUTO_LENGTH, &code);
+        napi_create_string_utf8(env, status == napi_ok ? j->msg : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, code, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j->o64);
+    free(j);
+}
+
+static napi_value BatchPackedAsync(napi_env env, napi_callback_info info) {
+    size_t argc = 9; napi_value argv[9];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 9) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "batchPackedAsync(handle, pcm, S, L, fftSize, hop, reassign, wire, offsets)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* pcm; size_t plen;
+    if (!get_typed(env, argv[1], napi_float32_array, &pcm, &plen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; int64_t L; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[3], &L));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[5], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[6], &argv[6]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[6], &reassign));
+    if (S < 1 || L < 1 || (size_t)S * (size_t)L != plen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pcm.length must equal S*L"); return NULL; }
+    void *wire = NULL, *offs = NULL; size_t wlen = 0, olen = 0;
+    if (!get_typed(env, argv[7], napi_uint8_array, &wire, &wlen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "wire must be a Uint8Array"); return NULL; }
+    if (!get_typed(env, argv[8], napi_float64_array, &offs, &olen, 0) || olen != (size_t)S + 1) {
+        napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "offsets must be a Float64Array(S + 1)"); return NULL;
+    }
+    packed_job* j = (packed_job*)calloc(1, sizeof(packed_job));
+    if (j) j->o64 = (int64_t*)malloc(sizeof(int64_t) * ((size_t)S + 1));
+    if (!j || !j->o64) { free(j); napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "out of host memory"); return NULL; }
+    j->e = h->e; j->pcm = (const float*)pcm; j->S = S; j->L = L; j->n = n; j->hop = hop; j->reassign = reassign ? 1 : 0;
+    j->C = emspec_num_columns(L, n, hop); j->wire = (uint8_t*)wire; j->wire_len = (int64_t)wlen; j->offs = (double*)offs;
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j->o64); free(j); napi_throw_error(env, "EMSPEC_NAPI", "napi_create_promise"); return NULL; }
+    napi_create_reference(env, argv[1], 1, &j->refs[0]);
+    napi_create_reference(env, argv[7], 1, &j->refs[1]);
+    napi_create_reference(env, argv[8], 1, &j->refs[2]);
+    napi_create_string_utf8(env, "emspec.batchPackedAsync", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, packed_execute, packed_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        for (int i = 0; i < 3; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+        free(j->o64); free(j);
+        napi_throw_error(env, "EMSPEC_NAPI", "could not queue async work");
+        return NULL;
+    }
+    return promise;
+}
+
 static napi_value SetColormap(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -664,6 +750,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"batch", NULL, Batch, NULL, NULL, NULL, napi_default, NULL},
         {"batchAsync", NULL, BatchAsync, NULL, NULL, NULL, napi_default, NULL},
         {"batchPacked", NULL, BatchPacked, NULL, NULL, NULL, napi_default, NULL},
+        {"batchPackedAsync", NULL, BatchPackedAsync, NULL, NULL, NULL, napi_default, NULL},
         {"wireUnpack", NULL, WireUnpack, NULL, NULL, NULL, napi_default, NULL},
         {"wireBound", NULL, WireBound, NULL, NULL, NULL, napi_default, NULL},
         {"setColormap", NULL, SetColormap, NULL, NULL, NULL, napi_default, NULL},

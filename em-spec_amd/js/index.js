@@ -76,6 +76,11 @@ class Engine {
     return native.batchPacked(this._h, pcm, S, L, fftSize, hop, !!reassign, wire, offsets);
   }
 
+  /** computeColumnsPacked off the JS thread (libuv pool): resolves with C; offsets are filled when it settles. */
+  computeColumnsPackedAsync(pcm, S, L, fftSize, hop, reassign, wire, offsets) {
+    return native.batchPackedAsync(this._h, pcm, S, L, fftSize, hop, !!reassign, wire, offsets);
+  }
+
   /** Same as computeColumns, off the JS thread: resolves with C.  Do not touch the arrays or this
    *  engine until the promise settles (an engine is not thread-safe). */
   computeColumnsAsync(pcm, S, L, fftSize, hop, reassign, out) {

@@ -214,6 +214,18 @@ async function checkAsync() {
   let rejected = false;
   try { await eng.computeColumnsAsync(pcm, 1, L, 3000, hop, true, { db: b }); } catch (e) { rejected = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
   if (!rejected) throw new Error('async error path');
+  // the packed entry off the JS thread: the image expands to the index columns of the synchronous call (float32 mode: +-1 cells)
+  const idx = new Uint8Array(frames * eng.rows), wire = new Uint8Array(em.wireBound(frames, eng.rows)), offs = new Float64Array(2);
+  eng.computeColumns(pcm, 1, L, fftSize, hop, true, { index: idx });
+  const Cp = await eng.computeColumnsPackedAsync(pcm, 1, L, fftSize, hop, true, wire, offs);
+  const back = new Uint8Array(frames * eng.rows);
+  em.unpackWire(wire.subarray(0, offs[1]), frames, eng.rows, back);
+  let off1 = 0;
+  for (let i = 0; i < idx.length; i++) { const d = Math.abs(idx[i] - back[i]); if (d > 1) throw new Error('packed async differs at ' + i); off1 += d; }
+  if (Cp !== frames || !(offs[1] > 32) || off1 > 1e-3 * idx.length) throw new Error('packed async: columns / offsets / +-1 share');
+  rejected = false;
+  try { await eng.computeColumnsPackedAsync(pcm, 1, L, fftSize, hop, true, wire.subarray(0, 64), offs); } catch (e) { rejected = e.code === 'EMSPEC_ERR_INVALID_ARG'; }
+  if (!rejected) throw new Error('packed async error path');
   const edges = em.warpedEdges(eng.rows, 30, 20000, 2.0, 1.5);
   eng.setRowEdges(edges);
   const got = eng.getRowEdges();
