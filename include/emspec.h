@@ -234,6 +234,11 @@ int emspec_reset(emspec_engine* e);
  * Batched throughput entry point, host buffers: S streams of L samples
  * (pcm[S][L], row-major) -> every finished column of every stream.
  * Copies in, runs the fused column kernel, copies the selected outputs back.
+ * When every buffer is page-locked (emspec_host_alloc) the call runs a three-stage pipeline over ~16 chunks of streams -
+ * host->device copies, kernels, device->host copies on three HIP streams of the engine - in either arithmetic mode and with
+ * the display post-process; what bounds it is PCIe (uint8 index out: ~45 GB/s each way at once on a Gen5 x16 link).
+ * Pageable buffers take one stream, chunk after chunk (staging bounded at 4 GiB).  Serves: the renderer-side batched
+ * computeColumns of the N-API addon (em-spec_amd/js/index.js).
  */
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
                  int32_t n, int32_t hop, int32_t reassign, const emspec_out* out);
