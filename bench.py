@@ -830,10 +830,11 @@ def main():
         # the bound the kernel really sits under, in the same shape as `roofline`: VALU issue in the cycle domain (a wave64
         # vector instruction holds its SIMD's pipe 2 cycles - 4 for binary64 - MI355X_MICROARCH.md), with the LDS pipe beside it
         if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
-            # float32 kernels: 2 cycles per wave64 instruction.  EXACT mode: binary64 fma / add / mul / compare hold the pipe 4 cycles,
-            # the rest (integer, float32, conversions, selects) 2; the ISA of exact_fused4096_kernel's frame loop is 48 % binary64
-            # (688 of 1,434 vector instructions, `make asm`), so the mix costs ~2.96 cycles; both extremes are given as well.
-            f64_share = 0.48 if args.mode == "exact" else 0.0
+            # float32 kernels: 2 cycles per wave64 instruction.  EXACT mode: binary64 fma / add / mul / compare hold the pipe 4 cycles
+            # (tools/ubench/f64_rate.hip: 4.06 measured), the rest (integer, float32, conversions, selects) 2; the ISA of
+            # exact_fused4096_lr_kernel's frame loop is 37 % binary64 (568 of 1,537 vector instructions, `make asm`; round 4's
+            # kernel: 48 % of 1,434 - its dB stage was binary64), so the mix costs ~2.74 cycles; both extremes are given as well.
+            f64_share = 0.37 if args.mode == "exact" else 0.0
             cyc = 2.0 + 2.0 * f64_share
             rate = prof["valu_insts_per_column"] * (S * C) / (k_avg_ms * 1e-3)
             peak = SIMDS * prof["clock_ghz"] * 1e9
