@@ -404,7 +404,7 @@ const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_st
 }  // extern "C"
 // EXACT mode, N = 4096: rows of the ring that the no-parking kernel (exact_fused_lr.hip.inc) keeps in global memory, or -1
 // when it does not serve this engine's shape or axis.  The axis is served when at most 6 % of a frame's bins lie below row
-// rl (on the default log axis at hop 256: rl = 440 of 1024 rows, 36 of 2,049 bins); each of those costs a device-scope
+// rl (on the default log axis at hop 256: rl = 448 of 1024 rows, 38 of 2,049 bins); each of those costs a device-scope
 // atomic, so a linear axis (44 % of the bins there) stays on round 4's kernel, which parks instead.
 static int exact_lr_rows(const emspec_engine* e, int n, const ExactPlanDev& pd) {
 #ifdef EMSPEC_DIAG

@@ -14,6 +14,7 @@ for p in (ROOT, os.path.join(ROOT, "em-spec_amd"), os.path.join(ROOT, "oracle"))
         sys.path.insert(0, p)
 import emspec  # noqa: E402
 import oracle as O  # noqa: E402
+import wire_ref as W  # noqa: E402
 from emspec import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +98,12 @@ def test_packed_batch_images_expand_to_the_plain_columns():
             for s in range(S):
                 got = emspec.wire_unpack_host(wire[offs[s]:offs[s + 1]], Cn, e.rows)
                 assert np.array_equal(got, ref[s]), s
+                # every byte of the image is specified (the payload's pad is zero): equal to the numpy restatement
+                assert np.array_equal(wire[offs[s]:offs[s + 1]], W.pack(ref[s])), s
+            first = wire[:offs[-1]].copy()
+            pw.array[...] = 0x5A                                  # whatever the buffer (and the staging) held before
+            wire, offs2 = e.batch_packed(pin.array, n, hop, True, wire=pw.array)
+            assert np.array_equal(offs2, offs) and np.array_equal(wire[:offs[-1]], first)
             # pageable buffers work too (slower), and so does a single stream
             w2, o2 = e.batch_packed(pcm[:1], n, hop, True)
             assert np.array_equal(emspec.wire_unpack_host(w2[:o2[1]], Cn, e.rows), ref[0])
