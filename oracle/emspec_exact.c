@@ -216,12 +216,20 @@ int eo_frames_exact(const eo_cfg* c, const float* pcm, int64_t L, int64_t frame0
     return 0;
 }
 
-/* stage "dB + colour", exact mode: 10 log10 through a SPECIFIED binary32 evaluation (no libm call; IEEE operations in this
- * order, fmaf where written, so the GPU and the CPU produce the same bits): x = m 2^e with m in (sqrt(1/2), sqrt 2],
- * s = (m-1)/(m+1), log2 m = (2/ln 2) s (1 + z/3 + z^2/5 + z^3/7 + z^4/9), z = s^2 (|s| <= 0.1716: truncation 2e-9, below
- * binary32's resolution).  Round 5: binary32 instead of binary64 - the outputs are a float32 dB and a palette byte, and on
- * MI355X a binary64 vector instruction costs four binary32 ones; the indices, the energies and their sums stay binary64 /
- * int64.  The cell's energy enters as (float)sum (int64 -> binary32, one rounding). */
+/* stage "dB + colour", exact mode: 10 log10 through a SPECIFIED binary32 evaluation (no libm call, no division; IEEE operations
+ * in this order, fmaf where written, so the GPU and the CPU produce the same bits): x = m 2^e with m in (sqrt(1/2), sqrt 2],
+ * f = m - 1 (exact), log2 m = f P(f) with P the degree-8 interpolant of log2(1+f)/f at the Chebyshev nodes of
+ * [sqrt(1/2)-1, sqrt(2)-1] (truncation 1.5e-8; with binary32 rounding the result is within 6.1e-8 of log2 m, tests/test_oracle.py).
+ * Binary32, not binary64: the outputs are a float32 dB and a palette byte, and on MI355X a binary64 vector instruction costs
+ * four binary32 ones; the indices, the energies and their sums stay binary64 / int64.  No division (until round 5's last form:
+ * the atanh series in s = (m-1)/(m+1)): a correctly rounded binary32 division is ten vector instructions on that hardware,
+ * and this stage's instruction count is part of what bounds the fused kernel.
+ * The cell's energy enters through eo_exact_sum32: the two 32-bit halves of the non-negative int64 sum, each converted
+ * exactly-or-rounded-once (u32 -> binary32), joined by one fmaf. */
+float eo_exact_sum32(int64_t sum) {
+    const uint64_t u = (uint64_t)sum;
+    return fmaf((float)(uint32_t)(u >> 32), 4294967296.0f, (float)(uint32_t)(u & 0xffffffffu));
+}
 float eo_exact_db32(float x) {
     union { float f; uint32_t u; } v;
     v.f = x;
@@ -229,14 +237,17 @@ float eo_exact_db32(float x) {
     v.u = (v.u & 0x007fffffu) | 0x3f800000u;
     float m = v.f;
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float z = s * s;
-    float pz = 1.0f / 9.0f;
-    pz = fmaf(pz, z, 1.0f / 7.0f);
-    pz = fmaf(pz, z, 1.0f / 5.0f);
-    pz = fmaf(pz, z, 1.0f / 3.0f);
-    pz = fmaf(pz, z, 1.0f);
-    float l2 = (s * pz) * 2.88539004f; /* 2 / ln 2 */
+    const float f = m - 1.0f;
+    float p = 0.123109683f;
+    p = fmaf(p, f, -0.205861881f);
+    p = fmaf(p, f, 0.216078222f);
+    p = fmaf(p, f, -0.239169881f);
+    p = fmaf(p, f, 0.287903249f);
+    p = fmaf(p, f, -0.360693276f);
+    p = fmaf(p, f, 0.480910748f);
+    p = fmaf(p, f, -0.721347451f);
+    p = fmaf(p, f, 1.44269502f);
+    const float l2 = f * p;
     return ((float)e + l2) * 3.01029992f; /* 10 log10(2) */
 }
 double eo_exact_db(double x) { return (double)eo_exact_db32((float)x); }
@@ -274,7 +285,7 @@ int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, cons
         }
         size_t base = (size_t)s * C * R;
         for (size_t i = 0; i < (size_t)C * R; ++i) {
-            float d = eo_exact_db32(fmaf((float)hist[i], sc, 1e-20f));
+            float d = eo_exact_db32(fmaf(eo_exact_sum32(hist[i]), sc, 1e-20f));
             float v = (d - lo) * inv_range;
             v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
             if (d < gate) v = 0.0f;

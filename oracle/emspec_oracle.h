@@ -79,6 +79,7 @@ int eo_batch_exact(const eo_cfg* c, const float* pcm, int32_t S, int64_t L, cons
                    uint8_t* rgba, uint8_t* index, int64_t* hist, int32_t threads);
 double eo_exact_db(double x);   /* = (double)eo_exact_db32((float)x) */
 float eo_exact_db32(float x);
+float eo_exact_sum32(int64_t sum);   /* the int64 cell sum -> binary32 (two u32 conversions + one fmaf) */
 
 /* emspec_cpu_fast.c: the same pipeline written for speed on a CPU (Stockham radix-4 FFT, ring histogram, vectorised
  * dB), for bench.py's cpu_baseline leg.  Not bit-identical to the bit model; checked against it at the test tolerance. */

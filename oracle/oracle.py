@@ -51,6 +51,8 @@ def lib():
         _lib.eo_max_threads.restype = C.c_int
         _lib.eo_exact_db.restype = C.c_double
         _lib.eo_exact_db.argtypes = [C.c_double]
+        _lib.eo_exact_sum32.restype = C.c_float
+        _lib.eo_exact_sum32.argtypes = [C.c_int64]
     return _lib
 
 
@@ -179,6 +181,11 @@ def batch_exact(cfg, pcm, lut=None, want=("db", "rgba", "index"), threads=0):
 
 def exact_db(x):
     return float(lib().eo_exact_db(float(x)))
+
+
+def exact_sum32(v):
+    """The int64 cell sum as the dB stage takes it in: binary32 from the two 32-bit halves (eo_exact_sum32)."""
+    return float(lib().eo_exact_sum32(int(v)))
 
 
 def max_threads():

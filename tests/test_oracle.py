@@ -290,6 +290,42 @@ def test_exact_db_polynomial():
     for x in kat:
         d = O.exact_db(x)
         assert d == float(np.float32(d))                 # a binary32 value
+    # the evaluation restated in numpy float32 (each fmaf = one rounding of the exact product-sum, which binary64 holds):
+    # mantissa folded into (sqrt 1/2, sqrt 2], f = m - 1, log2 m = f P(f), degree 8 - no division (round 5, last form)
+    coef = [0.123109683, -0.205861881, 0.216078222, -0.239169881, 0.287903249, -0.360693276, 0.480910748, -0.721347451, 1.44269502]
+    x32 = xs[:4000]
+    u = x32.view(np.uint32)
+    e = ((u >> 23) & 0xff).astype(np.int32) - 127
+    m = ((u & 0x007fffff) | 0x3f800000).view(np.float32)
+    big = m > np.float32(1.41421354)
+    m = np.where(big, m * np.float32(0.5), m).astype(np.float32)
+    e = e + big
+    f = (m - np.float32(1.0)).astype(np.float32)
+    p = np.full_like(f, np.float32(coef[0]))
+    for c in coef[1:]:
+        p = (p.astype(np.float64) * f.astype(np.float64) + np.float64(np.float32(c))).astype(np.float32)
+    l2 = (f * p).astype(np.float32)
+    want = ((e.astype(np.float32) + l2).astype(np.float32) * np.float32(3.01029992)).astype(np.float32)
+    got = np.array([O.exact_db(float(v)) for v in x32], np.float32)
+    assert np.array_equal(got, want)
+    l2err = np.max(np.abs(l2.astype(np.float64) - np.log2(m.astype(np.float64))))
+    assert l2err < 6.5e-8, l2err
+
+
+def test_exact_sum32_is_two_conversions_and_one_fma():
+    """The int64 cell sum enters the dB stage as fmaf((float)hi32, 2^32, (float)lo32): within 1.5 binary32 ulp of the sum,
+    exact below 2^24, and the same bits as the numpy restatement."""
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([rng.integers(0, 1 << 62, 3000), rng.integers(0, 1 << 33, 2000), [0, 1, (1 << 24) - 1, (1 << 32) - 1, 1 << 32, (1 << 63) - 1]])
+    for v in vals:
+        v = int(v)
+        hi, lo = np.float32(v >> 32), np.float32(v & 0xffffffff)
+        want = np.float32(np.float64(hi) * 4294967296.0 + np.float64(lo))    # exact in binary64, one rounding to binary32
+        got = O.exact_sum32(v)
+        assert got == float(want), v
+        assert abs(got - v) <= 1.5 * 2.0 ** -23 * max(v, 1)
+        if v < (1 << 24):
+            assert got == float(v)
 
 
 def test_exact_batch_is_order_independent_fixed_point():
