@@ -87,7 +87,7 @@ void cos_sin_octant(double a, double* c, double* s) {
 // (oracle/emspec_oracle.c: eo_spec_pow states the same operations)
 /* ratio^x by a SPECIFIED evaluation: exp2(x * log2(ratio)) from plain IEEE binary64 operations in this
  * order - no libm, whose pow() is not correctly rounded and differs between C libraries, so a table built from it would
- * depend on the host.  log2 as in the EXACT mode's dB (exact.hip.inc: exact_db) (atanh series on the mantissa folded into [1/sqrt2, sqrt2]); 2^f, |f| <= 1/2,
+ * depend on the host.  log2 by the atanh series on the mantissa folded into [1/sqrt2, sqrt2]; 2^f, |f| <= 1/2,
  * by the Taylor series of e^(f ln 2) in Horner form (truncation < 4e-18); scaling by 2^i is exact.  Within ~3 ulp of the
  * real value; what matters is that every build produces the same bits. */
 static double spec_log2(double x) {
