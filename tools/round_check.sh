@@ -1,8 +1,10 @@
 #!/bin/bash
 # Everything a round's numbers come from, on one MI355X box (run from the repo root through gpurun):
 #   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 a'   then   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 b'
-# (two calls since round 5: five profile sets + the suite no longer fit one 20-minute call; `a` = suite + the float32
-# workloads, `b` = the EXACT workloads + the stamped builds and rate tools)
+# (parts: `a` = suite + the float32 workloads, `b` = the EXACT workloads + the stamped builds and rate tools, `c` = the bench
+# lines; `abc` in one call keeps profiles and lines on one box - the profile JSONs a line quotes must already be in profiles/
+# for the counters to appear in it, so after a kernel change run `ab`, summarise + commit, then `abc` is not needed: run `c`
+# together with whatever profile the hygiene test flags)
 # 1. the GPU test suite; 2. rocprofv3 profiles of the two bench workloads (tools/profile_workload.sh: kernel trace +
 # separate PMC passes); 3. stamped-build phase cycles and the in-kernel clock; 4. gather cost; 5. host-API rates.
 # Afterwards, HERE:  python tools/profile_json.py gpurun_out/<tag>_batch64 <tag> batch64 1047616
@@ -43,5 +45,15 @@ timeout -k 10 200 python tools/kernel_clock.py > gpurun_out/${tag}_kernel_clock.
 timeout -k 10 200 python tools/gather_cost.py > gpurun_out/${tag}_gather_cost.txt 2>&1 || true
 timeout -k 10 300 python tools/host_rates.py > gpurun_out/${tag}_host_api_rate.txt 2>&1 || true
 timeout -k 10 300 python tools/host_pipeline_rates.py > gpurun_out/${tag}_host_pipeline_rate.txt 2>&1 || true
+fi
+if [[ $part == *c* ]]; then
+# the bench lines, on the SAME box as the profiles they quote (tests/test_bench_helpers.py holds every profile's median
+# duration to <= 1.02 x the line's kernel time: between boxes the clocks differ by more than that)
+cd "$R"
+python bench.py > gpurun_out/${tag}_bench_n1.json 2> gpurun_out/${tag}_bench_n1.err
+python bench.py --mode exact --no-configs > gpurun_out/${tag}_bench_exact.json 2>> gpurun_out/${tag}_bench_n1.err
+python bench.py --gather loopback --no-cpu-baseline --no-configs > gpurun_out/${tag}_bench_loopback.json 2>> gpurun_out/${tag}_bench_n1.err
+python bench.py --gather loopback --gather-expand --no-cpu-baseline --no-configs > gpurun_out/${tag}_bench_loopback_expand.json 2>> gpurun_out/${tag}_bench_n1.err
+echo "bench lines written"
 fi
 echo "round check ($part) written under gpurun_out/"
