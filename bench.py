@@ -832,9 +832,10 @@ def main():
         if prof and fresh and prof.get("valu_insts_per_column") and prof.get("clock_ghz"):
             # float32 kernels: 2 cycles per wave64 instruction.  EXACT mode: binary64 fma / add / mul / compare hold the pipe 4 cycles
             # (tools/ubench/f64_rate.hip: 4.06 measured), the rest (integer, float32, conversions, selects) 2; the ISA of
-            # exact_fused4096_lr_kernel's frame loop is 37 % binary64 (568 of 1,537 vector instructions, `make asm`; round 4's
-            # kernel: 48 % of 1,434 - its dB stage was binary64), so the mix costs ~2.74 cycles; both extremes are given as well.
-            f64_share = 0.37 if args.mode == "exact" else 0.0
+            # exact_fused4096_lr_kernel's frame loop is 41 % binary64 (568 of 1,369 vector instructions, `hipcc -S`; before the
+            # thread-constant address table and the division-free dB stage: 37 % of 1,537; round 4's kernel: 48 % of 1,434 - its
+            # dB stage was binary64), so the mix costs ~2.83 cycles; both extremes are given as well.
+            f64_share = 0.415 if args.mode == "exact" else 0.0
             cyc = 2.0 + 2.0 * f64_share
             rate = prof["valu_insts_per_column"] * (S * C) / (k_avg_ms * 1e-3)
             peak = SIMDS * prof["clock_ghz"] * 1e9
