@@ -369,8 +369,9 @@ int emspec_batch_gather(emspec_engine* e, const float* pcm, int32_t S, int64_t L
 
 /*
  * The wire image by itself, for hosts that bring their own transport: header (32 B) + a u32 payload offset per
- * column + ceil(rows/32) mask words per column + the non-zero indices (column after column, rows ascending), see
- * em-spec_amd/csrc/pack.hip.inc.
+ * column + ceil(rows/32) mask words per column + the non-zero indices (column after column, rows ascending), zero-padded
+ * to a multiple of 16 B: every byte of an image is specified, so equal columns give equal images (round 5; see
+ * em-spec_amd/csrc/pack.hip.inc, restated in oracle/wire_ref.py).
  * emspec_wire_bound: capacity a destination needs for `columns` columns (-1 on invalid arguments).
  * emspec_wire_pack:  index_dev [columns][rows] -> wire_dev; *wire_bytes (optional) = the image size (reading it
  *                    synchronises hip_stream; pass NULL to stay asynchronous).
