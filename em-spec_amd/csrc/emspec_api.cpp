@@ -628,7 +628,9 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     // the scatter's low-row scratch (exact.hip.inc: a ring too large for LDS is walked with its sparse low rows in global
     // memory); cleared once per batch - the kernel leaves it zero, this only guards against a launch that was cut short
     const float* ebin_host = p.h_ebin.data();
-    const size_t low_need = exact_scatter_scratch_bytes(n, pd, chunk, C, ebin_host);
+    // (the last chunk may hold fewer streams, and fewer streams are cut into more segments: size for both)
+    const size_t low_need = std::max(exact_scatter_scratch_bytes(n, pd, chunk, C, ebin_host),
+                                     S % chunk ? exact_scatter_scratch_bytes(n, pd, S % chunk, C, ebin_host) : (size_t)0);
     if (low_need) {
         if (low_need > e->xlow_bytes) {
             if (e->xlow_used) HIPCHK(e, hipEventSynchronize(e->xlow_event));
