@@ -121,6 +121,33 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = sm[pb + poff(i)];
         fft_stages_w<4, TwLdsSym16, PRIO>(v, TwLdsSym16{stw + lo, 1 << B0});   // PRIO builds (fused N = 16384) are also the register-lean ones
+        if constexpr (INPLACE && REM == 6) {
+            // The network's LAST TWO stages in registers (round 5): after this pass thread (hi, lo), lo = t & 3, holds
+            // positions 64 hi + lo + 4 i - the four positions of a radix-4 group of the last pass sit in the four lanes of a
+            // QUAD, same register.  Partners come through DPP quad permutes (lane ^ 2, then lane ^ 1; the compiler folds them
+            // into the adds), a - b is written partner + (-own) (the same IEEE result, signed zeros included), and the one
+            // non-trivial twiddle, -j on the group's fourth point, is a swap and a sign.  Same butterflies as
+            // fft_stages<LOG2N, S0 + 4, 2>; saves the network's last trip through LDS and its wave-local sync.
+            const int l4 = t & 3;
+            const unsigned s12 = (unsigned)(l4 & 2) << 30, s13 = (unsigned)(l4 & 1) << 31;
+            const bool rot = l4 == 3;
+            auto dpp = [](float x, auto ctrl) {
+                return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xF, 0xF, true));
+            };
+            auto neg_if = [](float x, unsigned m) { return __uint_as_float(__float_as_uint(x) ^ m); };
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pr = dpp(v[i].x, std::integral_constant<int, 0x4E>{}), pi = dpp(v[i].y, std::integral_constant<int, 0x4E>{});
+                const float dr = pr + neg_if(v[i].x, s12), di = pi + neg_if(v[i].y, s12);
+                const float ar = rot ? di : dr, ai = rot ? -dr : di;
+                const float qr = dpp(ar, std::integral_constant<int, 0xB1>{}), qi = dpp(ai, std::integral_constant<int, 0xB1>{});
+                v[i] = make_float2(qr + neg_if(ar, s13), qi + neg_if(ai, s13));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm[pb + poff(i)] = v[i];
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(3 - S0 / 4);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) sm[pb + poff(i)] = v[i];
         wave_lds_sync();
