@@ -477,7 +477,8 @@ def main():
         def dump():
             assert lib.emspec_parity_dump_device(eng._h, sub.data_ptr(), Sd, Ld, n, hop, 1, 0, Cd, pw_.data_ptr(), cl_.data_ptr(),
                                                  rw_.data_ptr(), C_.c_void_p(cur.cuda_stream)) == 0
-        for _ in range(max(args.warmup, 50)):      # a 0.7 ms kernel: >= 50 untimed launches let the clock settle on it (boxes differ by 20 % cold)
+        for _ in range(max(args.warmup, 200)):     # a 0.65 ms kernel: >= 200 untimed launches let the clock settle on it (boxes differ by 20 % cold;
+                                                   # 50 were not always enough under rocprofv3's serialised dispatches)
             dump()
         torch.cuda.synchronize(dev)
         ms = time_launches(dump, cur, args.steps)
