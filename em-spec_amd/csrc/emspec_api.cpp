@@ -623,7 +623,9 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     const size_t Kp = (size_t)exact_record_stride(n);
     const size_t q_per_stream = (size_t)C * Kp * sizeof(long long), key_per_stream = (size_t)C * Kp * sizeof(uint32_t);
     int chunk = 1;
-    if ((rc = grow_record_workspace(e, q_per_stream + key_per_stream, 256, (size_t)4 << 30, S, &chunk))) return rc;
+    // (8 GiB here, 4 GiB for the float32 records: the walking scatter reads a 2D-frame halo per segment, and a stream-chunk's
+    // segments get longer with the streams it holds - five streams of configs[4] per chunk: 23 % halo, ten: 12 %; 67.5 -> 66.1 ms per step, and 16 GiB measured 67.0)
+    if ((rc = grow_record_workspace(e, q_per_stream + key_per_stream, 256, (size_t)8 << 30, S, &chunk))) return rc;
     const size_t col_cells = (size_t)C * e->cfg.rows;
     // the scatter's low-row scratch (exact.hip.inc: a ring too large for LDS is walked with its sparse low rows in global
     // memory); cleared once per batch - the kernel leaves it zero, this only guards against a launch that was cut short
