@@ -1,10 +1,12 @@
 #!/bin/bash
 # Everything a round's numbers come from, on one MI355X box (run from the repo root through gpurun):
-#   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 a'   then   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 b'
-# (parts: `a` = suite + the float32 workloads, `b` = the EXACT workloads + the stamped builds and rate tools, `c` = the bench
-# lines; `abc` in one call keeps profiles and lines on one box - the profile JSONs a line quotes must already be in profiles/
-# for the counters to appear in it, so after a kernel change run `ab`, summarise + commit, then `abc` is not needed: run `c`
-# together with whatever profile the hygiene test flags)
+#   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 ab'    (after a kernel change: suite + profiles; ~3.5 GPU-minutes)
+#   HERE: the five profile_json.py lines below, commit profiles/<tag>_*.json
+#   gpurun --timeout 1200 -- 'bash tools/round_check.sh r05 abc'   (profiles AND bench lines on ONE box; summarise again, copy, commit)
+# Parts: `a` = suite + the float32 workloads, `b` = the EXACT workloads + the stamped builds and rate tools, `c` = the four
+# bench lines.  A line quotes the PMC counters only while profiles/<tag>_*.json carry the library's sources sha - hence the
+# first call - and tests/test_bench_helpers.py holds every profile's median duration to <= 1.02 x the line's kernel time, which
+# between boxes does not hold (their clocks differ by more) - hence `abc` in one call.
 # 1. the GPU test suite; 2. rocprofv3 profiles of the two bench workloads (tools/profile_workload.sh: kernel trace +
 # separate PMC passes); 3. stamped-build phase cycles and the in-kernel clock; 4. gather cost; 5. host-API rates.
 # Afterwards, HERE:  python tools/profile_json.py gpurun_out/<tag>_batch64 <tag> batch64 1047616
@@ -13,9 +15,6 @@
 #                    python tools/profile_json.py gpurun_out/<tag>_exact64 <tag> exact64 1047616
 #                    python tools/profile_json.py gpurun_out/<tag>_exact_n16384 <tag> exact_n16384 522304 --all-kernels
 #                    cp gpurun_out/<tag>_*.txt profiles/   and commit;
-# then a second call for the bench lines, which quote the counters only while profiles/<tag>_*.json match the kernels:
-#   gpurun -- 'python bench.py > gpurun_out/<tag>_bench_n1.json; python bench.py --gather loopback --no-cpu-baseline
-#              --no-configs > gpurun_out/<tag>_bench_loopback.json'
 set -e
 tag=${1:-r02}
 part=${2:-ab}
