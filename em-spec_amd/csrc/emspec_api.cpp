@@ -40,7 +40,7 @@ int grow(emspec_engine* e, void** ptr, size_t* have, size_t want) {
 }
 }  // namespace emspec
 
-namespace {
+namespace emspec {   // (internal linkage is not needed: the library exports only what emspec.map lists; emspec_live.cpp uses these)
 
 void default_lut(uint8_t* lut) {
     // 5-stop gradient measured from the reference's settings screenshot
@@ -291,7 +291,7 @@ DbMap db_map(const emspec_engine* e, int n) {
     return m;
 }
 
-}  // namespace
+}  // namespace emspec
 
 static void drop_plans(emspec_engine* e);
 
@@ -364,6 +364,7 @@ void emspec_destroy(emspec_engine* e) {
     if (e->stream_in) (void)hipStreamSynchronize(e->stream_in);
     if (e->stream_out) (void)hipStreamSynchronize(e->stream_out);
     comm_destroy(e);
+    live_destroy(e);
     drop_plans(e);
     (void)hipFree(e->d_xlow);
     if (e->xlow_event) (void)hipEventDestroy(e->xlow_event);
@@ -441,6 +442,8 @@ static void drop_plans(emspec_engine* e) {
 int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
     if (e->st_reassign >= 0 && e->st_fed > e->st_emitted) return fail(e, EMSPEC_ERR_STATE, "columns are pending; flush or reset before changing the row edges");
+    for (int s = 0; s < e->live.S; ++s)
+        if (e->live.fed[s] > e->live.emitted[s]) return fail(e, EMSPEC_ERR_STATE, "columns of the live session are pending; flush or reset before changing the row edges");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (!edges_hz) {   // back to the configured log axis
@@ -976,7 +979,7 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     return EMSPEC_OK;
 }
 
-static bool host_pinned(const void* p) {
+bool emspec::host_pinned(const void* p) {
     if (!p) return true;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -1181,6 +1184,7 @@ int emspec_reset(emspec_engine* e) {
     e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0; e->st_W = 0; e->st_mode = 0;
     e->st_fed = 0; e->st_emitted = 0; e->st_have = 0;
     e->st_pending.clear();
+    live_reset(e);
     return EMSPEC_OK;
 }
 

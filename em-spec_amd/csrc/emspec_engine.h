@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+struct emspec_engine;
 namespace emspec {
 struct Plan {
     int n = 0;
@@ -22,6 +23,41 @@ struct Plan {
     double* d_ebin64 = nullptr;
     double h_e0 = 0.0, h_eR = 0.0;   // ends of the binary64 edge table
 };
+// Live multi-stream streaming session (emspec_live.cpp; include/emspec.h: emspec_columns / emspec_push_samples_multi):
+// S streams, each with its own sample position, sample ring and pending-column ring, advanced together by ONE launch per call.
+struct LiveState {
+    int S = 0, n = 0, hop = 0, reassign = -1, D = 0;
+    int form = 0;             // 0 none, 1 per-frame (emspec_columns), 2 per-sample-block (emspec_push_samples_multi)
+    int slots = 0;            // column-ring slots per stream: 2 D + mmax
+    int mmax = 0;             // frames per stream and launch, at most
+    int64_t cap = 0;          // samples per stream the staging block holds (form 2: mmax * hop)
+    int ring_mask = 0;        // device sample ring per stream: ring_mask + 1 >= n + cap samples (form 2)
+    std::vector<int64_t> fed, emitted, seen, newbase;   // per stream: frames fed, columns emitted, samples received, samples in the device ring
+    std::vector<int> pend;    // per stream: samples waiting in the staging block
+    void* d_cells = nullptr; size_t cells_bytes = 0;    // [S][slots][rows] float32 (FAST) / u64 (EXACT)
+    float* d_sring = nullptr; size_t sring_bytes = 0;   // [S][ring_mask + 1]
+    unsigned* d_done = nullptr; size_t done_bytes = 0;  // [S] arrival counters
+    float* d_raw = nullptr; size_t raw_bytes = 0;       // display post-process: raw dB [S][mmax][rows]
+    float* d_pstate = nullptr; size_t pstate_bytes = 0; // display post-process: [S][rows + 4] (AGC level, initialised, -, -, previous column)
+    // page-locked, device-visible host buffers: descriptors [S], staging samples [S][cap], staging outputs [S][mmax][rows]
+    void* h_desc = nullptr; size_t desc_bytes = 0;
+    float* h_fresh = nullptr; size_t fresh_bytes = 0;
+    float* h_odb = nullptr; size_t odb_bytes = 0;
+    uint8_t* h_orgba = nullptr; size_t orgba_bytes = 0;
+};
+
+// emspec_api.cpp: the plan cache and the per-shape constants handed to the kernels
+int latency(int n, int hop, int reassign);
+int check_shape(const emspec_engine* e, int n, int hop);
+int get_plan(emspec_engine* e, int n, Plan** out);
+PlanDev plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign);
+ExactPlanDev exact_plan_dev(const emspec_engine* e, const Plan& p, int hop, int reassign);
+ExactDbMap exact_db_map(const emspec_engine* e, int n, const ExactPlanDev& pd);
+DbMap db_map(const emspec_engine* e, int n);
+bool host_pinned(const void* p);   // p is null or page-locked host memory the device can address
+void live_destroy(emspec_engine* e);   // emspec_live.cpp: called by emspec_destroy
+void live_reset(emspec_engine* e);     // drops the live session's stream state (emspec_reset); buffers are kept
+bool live_active(const emspec_engine* e);
 }  // namespace emspec
 
 struct emspec_engine {
@@ -81,6 +117,7 @@ struct emspec_engine {
     float* d_post = nullptr; size_t post_bytes = 0;    // post-processed dB when the caller wants none
     float* d_peak = nullptr; size_t peak_bytes = 0;    // column peaks + gains
     float* d_pstate = nullptr;                         // streaming: [0]=AGC level, [1]=initialised, [2..]=previous column
+    emspec::LiveState live;   // live multi-stream streaming (emspec_live.cpp)
     // multi-GPU gather of finished columns (emspec_comm.cpp); opaque here so this header needs no rccl.h
     struct emspec_comm_state* comm = nullptr;
 };

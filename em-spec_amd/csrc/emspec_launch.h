@@ -6,6 +6,34 @@
 
 namespace emspec {
 
+// ---- live multi-stream streaming (emspec_columns / emspec_push_samples_multi; live.hip.inc) ----
+// One launch serves S live streams: grid = (frames per stream + 1, S).  Workgroup (f, s) with f < frames[s] transforms
+// frame j0[s] + f of stream s and scatters it into that stream's column ring in HBM (device-scope atomics); the LAST of a
+// stream's workgroups to finish (an arrival counter per stream) finalises the columns the launch completed, straight into the
+// caller's (page-locked) output, and clears their ring slots.  Workgroup (gridDim.x - 1, s) moves the stream's new samples
+// from the page-locked staging block into its device sample ring for later launches.
+struct LiveStream {        // per stream and launch; read by the kernel from page-locked host memory
+    long long j0;          // absolute index of the stream's first frame in this launch (= frames fed so far)
+    long long newbase;     // absolute index of fresh[s][0]: samples below it are in the device sample ring
+    int frames;            // frames of this stream in this launch (0 .. gridDim.x - 1)
+    int newcount;          // samples in fresh[s] to move into the sample ring
+    int out_at;            // first column slot of the stream's output block this launch writes
+    int flush;             // != 0: no frames; finalise `flush` pending columns starting at column j0 - D (emspec_columns_flush)
+};
+struct LiveSinks {
+    const LiveStream* streams = nullptr;   // [S]; null: not a live launch
+    const float* fresh = nullptr;          // [S][fresh_stride] samples the device ring does not hold yet
+    long long fresh_stride = 0;
+    float* sring = nullptr;                // [S][ring_mask + 1] device sample ring: absolute sample a sits at a & ring_mask
+    int ring_mask = 0;
+    unsigned* done = nullptr;              // [S] arrival counters, zero between launches
+    float* out_db = nullptr;               // [S][out_cols][rows], or null
+    uint32_t* out_rgba = nullptr;          // [S][out_cols][rows] RGBA8, or null
+    int out_cols = 0;
+    int empty_col = 0;                     // per-frame form: a frame that completes no column yet emits the empty column
+    const uint32_t* lut = nullptr;
+};
+
 // Where frames_kernel sends its per-bin results.
 struct FrameSinks {
     // parity dump (all three or none): [stream][frame][K]
@@ -28,6 +56,7 @@ struct FrameSinks {
     const uint32_t* fin_lut = nullptr;
     int64_t fin_col = -1;
     DbMap fin_map{};
+    LiveSinks live{};                 // live multi-stream launch (uses hist / hist_slots / fin_map)
 };
 
 // Where the exact-mode frame kernels send their per-bin results (exact.hip.inc)
@@ -48,6 +77,8 @@ struct ExactSinks {
     int32_t ring = 0;
     int64_t col_offset = 0;
     int32_t edges_lds = 1;     // set by the launcher: the binary64 edge table is staged in LDS (0: read from global memory)
+    LiveSinks live{};          // live multi-stream launch (uses hist / hist_slots / fin_map)
+    ExactDbMap fin_map{};
 };
 hipError_t launch_exact_frames(int n, const ExactPlanDev& pl, const float* pcm, int64_t L, int S, int64_t frame0,
                                int64_t nframes, const ExactSinks& sinks, hipStream_t st);
@@ -107,6 +138,13 @@ hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uin
                               float* gain, hipStream_t st);
 hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut,
                               uint8_t* rgba, float* state, float* yprev, hipStream_t st);
+// live multi-stream calls (live_launch.hip.inc): flush of pending columns, display post-process of a launch's columns.
+// The frame launches themselves go through launch_frames / launch_exact_frames with sinks.live set and
+// nframes = (largest per-stream frame count) + 1.
+hipError_t launch_live_flush(bool exact, const LiveSinks& lv, void* cells, int slots, int rows, int D, const DbMap& m,
+                             const ExactDbMap& xm, int S, hipStream_t st);
+hipError_t launch_live_post(const LiveSinks& lv, const float* raw, int rows, int D, float sm, float agc, float db_top,
+                            const DbMap& dm, float* pstate, int S, hipStream_t st);
 // the gather's wire image (pack.hip.inc)
 int64_t wire_bound_bytes(int64_t columns, int rows);
 int64_t wire_fixed_bytes(int64_t columns, int rows);

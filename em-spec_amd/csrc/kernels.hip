@@ -12,6 +12,7 @@
 //   finalize_kernel        histogram -> dB / RGBA / palette index.
 //   fused kernels          see fused.hip.inc (LDS column ring, batch path).
 #include "emspec_launch.h"
+#include "live.hip.inc"
 
 #include <algorithm>
 #include <cstdlib>
@@ -191,7 +192,9 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
 }
 
 // SINK: which outputs are compiled in.  0 = whatever the FrameSinks say at run time (the streaming call: histogram
-// atomics + the finished column); 1 = the parity dump only; 2 = the records for the tile scatter only.  With the
+// atomics + the finished column); 1 = the parity dump only; 2 = the records for the tile scatter only; 3 = a live
+// multi-stream launch (live.hip.inc: per-stream frame counts, samples from the ring / the staging block, ring atomics,
+// the stream's last workgroup finalises).  With the
 // run-time form every bin re-tests five sink pointers and recomputes three 64-bit frame offsets on the scalar unit -
 // a few hundred instructions of each wave's stream per frame.
 // FASTC: the plan is "fast" (emspec_plan_is_fast): the branch-free per-bin core.
@@ -209,13 +212,20 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     // share 15/16 of their samples - would land on different L2s and every L2 would fetch about half of every frame
     // (PMC: 8.3 KB read per column against 1 KB algorithmic).  Re-deal them: XCD x takes the x-th eighth of the
     // (stream, frame) sequence, a contiguous run, and the overlap is served by that XCD's L2.
+    int64_t f;                             // frame within the launch
+    int s;                                 // stream
+    int64_t j, jcol;                       // frame within the pcm buffer; its own absolute column
+    LiveBlock lb;                          // live multi-stream launch (live.hip.inc): per-stream frame counts and sample sources
+    constexpr bool live = SINK == 3;       // 3 = the run-time form of a live multi-stream launch
+    if (live) {
+        if (!lb.init(sk.live, pl.hop, T)) return;
+        s = lb.s; f = lb.f; j = f; jcol = lb.column();
+    } else {
     const int64_t total = (int64_t)gridDim.x * gridDim.y, lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int64_t full = total & ~(int64_t)7;
     const int64_t work = lin < full ? (lin & 7) * (full >> 3) + (lin >> 3) : lin;
     // (32-bit division whenever the launch has fewer than 2^32 workgroups, i.e. always in practice: a 64-bit division or
     // modulo is ~140 scalar instructions on this hardware, and every workgroup - one frame - paid two of them)
-    int64_t f;                             // frame within the launch
-    int s;                                 // stream
     if (total <= 0xFFFFFFFFll) {
         const unsigned w32 = (unsigned)work, q32 = w32 / gridDim.x;
         s = (int)q32;
@@ -224,8 +234,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         f = work % gridDim.x;
         s = (int)(work / gridDim.x);
     }
-    const int64_t j = frame0 + f;          // frame within the pcm buffer
-    const int64_t jcol = j + sk.col_offset; // its own absolute column
+    j = frame0 + f;
+    jcol = j + sk.col_offset;
+    }
 
     for (int r = t; r <= pl.rows; r += T) seb[r] = pl.ebin[r];
     stage_mid_twiddles<LOG2N, 4>(stw, pl.tw, t, T);
@@ -237,7 +248,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int n = t + T * i;
-        const float xv = x[n];
+        const float xv = live ? lb.sample(n) : x[n];
         v[i] = make_float2(xv, xv * ((float)(n - N / 2) * rs));
     }
     // stage "STFT": first pass (stages 0..3) straight from registers
@@ -251,10 +262,13 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     HintLookup lk;
     lk.init(seb, pl.ebin, pl.rows, pl.log_rows);
     const size_t fidx = (size_t)s * nframes + f;                   // this frame's index in the per-frame output arrays
-    float* const out_power = (SINK == 1 || (SINK == 0 && sk.power)) ? sk.power + fidx * K : nullptr;
+    float* const out_power = (SINK == 1 || (SINK == 0 && sk.power)) ? sk.power + fidx * K : nullptr;   // (SINK 3: ring only)
     int32_t* const out_col = out_power ? sk.col + fidx * K : nullptr;
     int32_t* const out_row = out_power ? sk.row + fidx * K : nullptr;
     uint2* const out_rec = (SINK == 2 || (SINK == 0 && sk.records)) ? sk.records + fidx * (K + 1) : nullptr;
+    // ring slot of this frame's own column (ring sinks): a bin lands at most D < slots columns away, so its slot is an add
+    // and a wrap instead of a 64-bit modulo per bin
+    const int slot_j = ((SINK == 0 || SINK == 3) && sk.ring) ? (int)(jcol % sk.hist_slots) : 0;
     auto do_bin = [&](int k, int pzm, int pz0, int pzp, int pwm, int pw0, int pwp) {
         const float2 zm = sm[pzm], z0 = sm[pz0], zp = sm[pzp];
         const float2 wm = sm[pwm], w0 = sm[pw0], wp = sm[pwp];
@@ -272,9 +286,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
             out_rec[k] = make_uint2(__float_as_uint(o.power), key);
             if (k == N / 2) out_rec[k + 1] = make_uint2(0u, 0xFFFFFFFFu);
         }
-        if constexpr (SINK == 0) {
+        if constexpr (SINK == 0 || SINK == 3) {
             if (sk.hist && o.row >= 0 && col >= 0 && col < sk.total_cols) {
-                const int64_t slot = sk.ring ? (col % sk.hist_slots) : col;
+                const int64_t slot = sk.ring ? (int64_t)live_slot(slot_j, o.dcol, (int)sk.hist_slots) : col;
                 atomicAdd(sk.hist + ((size_t)s * sk.hist_slots + slot) * pl.rows + o.row, o.power);
             }
         }
@@ -299,6 +313,11 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
             do_bin(t + T * i, bzm + T * i, bz0 + T * i, bzp + T * i, bwm - T * i, bw0 - T * i, bwp - T * i);
     }
     if (t == 0) do_bin_general(N / 2);                             // the Nyquist bin
+    if constexpr (SINK == 3) {
+        if (live_last_arrival(sk.live, s, lb.d.frames, sm))
+            live_finalize<float>(sk.live, lb.d, s, sk.hist, (int)sk.hist_slots, pl.rows, pl.D, T, LiveConvF32{sk.fin_map});
+        return;
+    }
     if constexpr (SINK != 0) return;
     if (sk.fin_db || sk.fin_rgba) {
         // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
@@ -331,10 +350,11 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // the sink combination picks the build: dump only, records only, or the run-time form
     const bool plain = !sk.hist && !sk.fin_db && !sk.fin_rgba;
-    const int sink = (plain && sk.power && !sk.records) ? 1 : ((plain && sk.records && !sk.power) ? 2 : 0);
+    const int sink = sk.live.streams ? 3 : (plain && sk.power && !sk.records) ? 1 : ((plain && sk.records && !sk.power) ? 2 : 0);
     const bool fastc = sink != 0 && emspec_plan_is_fast(pl);
     const void* fn = sink == 1 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1>))
                    : sink == 2 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2>))
+                   : sink == 3 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3>))
                                : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 0>);
     if (lds > 64 * 1024) {
         const hipError_t e = allow_max_lds(fn);
@@ -348,6 +368,8 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     else if (sink == 1) hipLaunchKernelGGL((frames_kernel<LOG2N, 1>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     else if (sink == 2 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 2, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     else if (sink == 2) hipLaunchKernelGGL((frames_kernel<LOG2N, 2>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else if (sink == 3 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 3, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else if (sink == 3) hipLaunchKernelGGL((frames_kernel<LOG2N, 3>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     else hipLaunchKernelGGL((frames_kernel<LOG2N, 0>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     return hipGetLastError();
 }
@@ -683,3 +705,4 @@ hipError_t launch_occupy(int groups, int usec, unsigned* sink, hipStream_t st) {
 #include "exact.hip.inc"
 #include "exact_fused.hip.inc"
 #include "exact_fused_lr.hip.inc"
+#include "live_launch.hip.inc"

@@ -37,6 +37,8 @@ SYMBOLS = [
     "emspec_gather_columns", "emspec_wire_bound", "emspec_wire_pack", "emspec_wire_unpack", "emspec_batch_gather",
     "emspec_parity_dump_exact", "emspec_gather_packed_layout", "emspec_mode", "emspec_build_info", "emspec_device_status",
     "emspec_comm_set_timeout", "emspec_batch_packed", "emspec_wire_unpack_host",
+    "emspec_columns", "emspec_columns_flush", "emspec_push_columns_multi", "emspec_push_samples_multi",
+    "emspec_reset_stream", "emspec_live_streams",
 ]
 
 
@@ -147,6 +149,16 @@ def load(diag=False):
     lib.emspec_build_info.restype = C.c_char_p
     lib.emspec_device_status.argtypes = [C.c_void_p]
     lib.emspec_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
+    lib.emspec_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_int32, C.c_void_p]
+    lib.emspec_columns_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.emspec_push_columns_multi.restype = C.c_int64
+    lib.emspec_push_columns_multi.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    lib.emspec_push_samples_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.emspec_reset_stream.argtypes = [C.c_void_p, C.c_int32]
+    lib.emspec_live_streams.argtypes = [C.c_void_p]
+    lib.emspec_live_streams.restype = C.c_int32
     _libs[diag] = lib
     return lib
 
@@ -512,3 +524,69 @@ class Engine:
 
     def reset(self):
         self._chk(self._lib.emspec_reset(self._h))
+
+    # -- live multi-stream streaming: S streams per call, one launch ------------------
+    @property
+    def live_streams(self):
+        return int(self._lib.emspec_live_streams(self._h))
+
+    def _live_out(self, S, cols, want_db, want_rgba, db, rgba):
+        shape = (S, self.rows) if cols is None else (S, cols, self.rows)
+        if db is None and want_db:
+            db = np.empty(shape, np.float32)
+        if rgba is None and want_rgba:
+            rgba = np.empty(shape + (4,), np.uint8)
+        assert db is None or (db.dtype == np.float32 and db.flags.c_contiguous and db.shape == shape)
+        assert rgba is None or (rgba.dtype == np.uint8 and rgba.flags.c_contiguous and rgba.shape == shape + (4,))
+        return db, rgba
+
+    def columns(self, frames, hop, reassign=True, want_db=True, want_rgba=False, db=None, rgba=None):
+        """Per-frame form (emspec_columns): frames [S][n], one frame of every stream -> (db [S][rows] or None,
+        rgba [S][rows][4] or None, columns int64 [S] (-1 = the empty column)).  db / rgba: optional preallocated
+        (page-locked: PinnedArray.array) outputs."""
+        frames = frames if isinstance(frames, np.ndarray) and frames.dtype == np.float32 and frames.flags.c_contiguous \
+            else np.ascontiguousarray(frames, np.float32)
+        S, n = frames.shape
+        db, rgba = self._live_out(S, None, want_db, want_rgba, db, rgba)
+        cols = np.empty(S, np.int64)
+        self._chk(self._lib.emspec_columns(self._h, _np_ptr(frames), S, n, hop, int(bool(reassign)), _np_ptr(db), _np_ptr(rgba),
+                                           self.rows, _np_ptr(cols)))
+        return db, rgba, cols
+
+    def columns_flush(self, want_db=True, want_rgba=False, db=None, rgba=None):
+        S = self.live_streams
+        db, rgba = self._live_out(S, None, want_db, want_rgba, db, rgba)
+        cols = np.empty(S, np.int64)
+        self._chk(self._lib.emspec_columns_flush(self._h, _np_ptr(db), _np_ptr(rgba), self.rows, _np_ptr(cols)))
+        return db, rgba, cols
+
+    def push_columns_multi(self, count, n, hop, reassign=True):
+        return int(self._lib.emspec_push_columns_multi(self._h, count, n, hop, int(bool(reassign))))
+
+    def push_samples_multi(self, samples, n, hop, reassign=True, want_db=True, want_rgba=False, db=None, rgba=None,
+                           count=None, offset=0):
+        """Per-sample-block form (emspec_push_samples_multi): samples [S][>= offset + count] (a window [offset, offset + count)
+        of every row is fed) -> (db [S][k][rows], rgba, counts int64 [S], first_columns int64 [S]); k = the largest per-stream
+        count (or the second dimension of the preallocated db / rgba)."""
+        samples = samples if isinstance(samples, np.ndarray) and samples.dtype == np.float32 and samples.flags.c_contiguous \
+            else np.ascontiguousarray(samples, np.float32)
+        S, width = samples.shape
+        if count is None:
+            count = width - offset
+        assert 0 <= offset and offset + count <= width
+        k = self.push_columns_multi(count, n, hop, reassign)
+        if k < 0:
+            raise EmspecError(ERR_INVALID_ARG, "invalid fft size / hop")
+        if db is not None:
+            k = db.shape[1]
+        elif rgba is not None:
+            k = rgba.shape[1]
+        db, rgba = self._live_out(S, k, want_db, want_rgba, db, rgba)
+        counts, firsts = np.empty(S, np.int64), np.empty(S, np.int64)
+        base = C.c_void_p(samples.ctypes.data + 4 * offset)
+        self._chk(self._lib.emspec_push_samples_multi(self._h, base, S, count, width, n, hop, int(bool(reassign)), _np_ptr(db),
+                                                      _np_ptr(rgba), self.rows, k, _np_ptr(counts), _np_ptr(firsts)))
+        return db, rgba, counts, firsts
+
+    def reset_stream(self, stream):
+        self._chk(self._lib.emspec_reset_stream(self._h, stream))

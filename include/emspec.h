@@ -83,7 +83,8 @@ typedef struct emspec_config {
  *                      binary64 evaluation a few 1e-4 of the bins that sit on a cell edge land in the neighbouring
  *                      cell, and cells are summed in arrival order (dB reproducible to a few ulp).
  *   EMSPEC_MODE_EXACT  binary64 from the frame to the indices, energy summed in 64-bit fixed point (order-
- *                      independent), dB through a specified binary64 polynomial: (column,row) agree
+ *                      independent), dB through a specified binary32 evaluation (no library call, no division; DESIGN.md 3.7;
+ *                      within 2e-5 dB of the real value): (column,row) agree
  *                      with a float64 implementation of the three-window method on every bin, and dB / palette index /
  *                      RGBA are bit-reproducible run to run and equal to the CPU bit model's bytes (every table - twiddles,
  *                      log-spaced row edges, dB polynomial - is a specified sequence of IEEE operations, no libm call, so the
@@ -91,7 +92,7 @@ typedef struct emspec_config {
  *                      float64 implementation on every bin" is a measured statement: 0 mismatches in > 10^8 values, where
  *                      two binary64 evaluations may still differ on a bin within ~1e-13 of an edge).  Inputs must stay
  *                      within |x| <= 4 (the fixed point covers 2^11 full-scale-sine powers per cell).  Same entry points;
- *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 2.6x slower than the fast mode at N = 4096.
+ *                      emspec_parity_dump_exact replaces emspec_parity_dump.  Roughly 2.1x slower than the fast mode at N = 4096.
  */
 #define EMSPEC_MODE_FAST 0
 #define EMSPEC_MODE_EXACT 1
@@ -227,8 +228,49 @@ int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count,
                         uint8_t* out_rgba, int32_t rows, int64_t max_columns,
                         int64_t* out_count, int64_t* out_first_column);
 
-/* Drop all per-stream state (sample position, pending ring). */
+/* Drop all per-stream state (sample position, pending ring), of the single-stream calls above and of the live
+ * multi-stream session below. */
 int emspec_reset(emspec_engine* e);
+
+/*
+ * ---- Live multi-stream streaming: S streams advance together, ONE kernel launch and ONE synchronisation per call.
+ * Serves: BASELINE.json configs[2] ("64 concurrent 48 kHz streams") in the form the renderer calls it - north_star's
+ * per-frame computeSpectrogramColumn(audioFrame, fftSize, hop, reassign), README.md:36 ("automatically start visualizing
+ * your system audio") - where one engine per stream would cost S launches + S synchronisations per hop on the host
+ * thread.  [BUILD-DEFINED]; same arithmetic, same results as emspec_column / emspec_push_samples / emspec_batch on every
+ * stream (FAST mode: the float32 sums are taken in arrival order, dB equal to a few ulp; EXACT mode: equal bytes).
+ *
+ * The first call fixes the session: streams, fft size, hop, reassign and the feeding form (per frame OR per sample block);
+ * changing any of them later is EMSPEC_ERR_STATE until emspec_reset().  The session is independent of the single-stream
+ * state of emspec_column / emspec_push_samples.  Every stream has its own position: emspec_reset_stream(e, s) restarts
+ * stream s (its sample position, pending columns and display post-process state) while the others continue.
+ * Buffers: any host memory works; when a buffer is page-locked (emspec_host_alloc) the kernel reads / writes it in place
+ * (no staging copy on the host thread) - for 64 streams of n = 4096 that is 1 MB of frames per emspec_columns call.
+ *
+ * emspec_columns: per-frame form.  frames[streams][n]: frame j_s of each stream (stream s has been fed j_s frames so far).
+ *   out_db[streams][rows] / out_rgba[streams][rows][4] (each may be NULL) receive column j_s - D of every stream
+ *   (D = emspec_latency_columns), the empty column while a stream's ring primes; out_columns[streams] (optional) the
+ *   column index, -1 for the empty column.
+ * emspec_columns_flush: every stream that still has pending columns emits its next one (others: the empty column, -1).
+ *   EMSPEC_ERR_STATE when no stream has any.  Works for both feeding forms.
+ * emspec_push_samples_multi: per-sample-block form.  samples: `count` new samples of every stream, stream s at
+ *   samples + s * stride (stride >= count: a window of a larger [streams][...] array works).  Finished columns of stream s
+ *   go to out_db[s][0 .. out_counts[s]) of out_db[streams][max_columns][rows] (and / or out_rgba, same layout + [4]),
+ *   oldest first; out_first_columns[s] = absolute index of the first, -1 if none.  No empty columns.  A block that
+ *   completes more than max_columns columns on some stream is rejected before any state changes
+ *   (emspec_push_columns_multi = the largest per-stream count a block of `count` samples will complete).  Blocks that
+ *   complete no frame only join a staging block on the host: no launch.
+ * emspec_live_streams: streams of the current session (0 = none).
+ */
+int emspec_columns(emspec_engine* e, const float* frames, int32_t streams, int32_t n, int32_t hop, int32_t reassign,
+                   float* out_db, uint8_t* out_rgba, int32_t rows, int64_t* out_columns);
+int emspec_columns_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba, int32_t rows, int64_t* out_columns);
+int64_t emspec_push_columns_multi(const emspec_engine* e, int64_t count, int32_t n, int32_t hop, int32_t reassign);
+int emspec_push_samples_multi(emspec_engine* e, const float* samples, int32_t streams, int64_t count, int64_t stride,
+                              int32_t n, int32_t hop, int32_t reassign, float* out_db, uint8_t* out_rgba, int32_t rows,
+                              int64_t max_columns, int64_t* out_counts, int64_t* out_first_columns);
+int emspec_reset_stream(emspec_engine* e, int32_t stream);
+int32_t emspec_live_streams(const emspec_engine* e);
 
 /*
  * Batched throughput entry point, host buffers: S streams of L samples
