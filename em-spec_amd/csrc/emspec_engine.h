@@ -44,6 +44,7 @@ struct LiveState {
     float* h_fresh = nullptr; size_t fresh_bytes = 0;
     float* h_odb = nullptr; size_t odb_bytes = 0;
     uint8_t* h_orgba = nullptr; size_t orgba_bytes = 0;
+    unsigned long long* stamps = nullptr;   // diagnostic build: [S][8] page-locked, set by emspec_debug_live_stamps
 };
 
 // emspec_api.cpp: the plan cache and the per-shape constants handed to the kernels

@@ -22,6 +22,8 @@ struct LiveStream {        // per stream and launch; read by the kernel from pag
 };
 struct LiveSinks {
     const LiveStream* streams = nullptr;   // [S]; null: not a live launch
+    LiveStream uni{};                      // uniform != 0: every stream's descriptor (the kernel then does not read `streams`)
+    int uniform = 0;
     const float* fresh = nullptr;          // [S][fresh_stride] samples the device ring does not hold yet
     long long fresh_stride = 0;
     float* sring = nullptr;                // [S][ring_mask + 1] device sample ring: absolute sample a sits at a & ring_mask
@@ -32,6 +34,9 @@ struct LiveSinks {
     int out_cols = 0;
     int empty_col = 0;                     // per-frame form: a frame that completes no column yet emits the empty column
     const uint32_t* lut = nullptr;
+#ifdef EMSPEC_DIAG
+    unsigned long long* stamps = nullptr;  // [S][8] 100 MHz wall-clock stamps of each stream's first workgroup (tools/live_phases.py)
+#endif
 };
 
 // Where frames_kernel sends its per-bin results.

@@ -10,6 +10,11 @@
 // No reference file:line exists (the reference source is private, README.md:73); SURVEY.md §8(f) row 4 is the streaming glue.
 // Device side: live.hip.inc / live_launch.hip.inc.
 #include "emspec_engine.h"
+#ifdef EMSPEC_DIAG
+#pragma GCC visibility push(default)
+#include "../../include/emspec_debug.h"
+#pragma GCC visibility pop
+#endif
 
 #include <algorithm>
 #include <cstring>
@@ -113,6 +118,16 @@ int live_launch(emspec_engine* e, const float* fresh, int64_t fresh_stride, int 
     ls.out_cols = out_cols;
     ls.empty_col = empty_col ? 1 : 0;
     ls.lut = reinterpret_cast<const uint32_t*>(e->d_lut);
+    {   // every stream in the same state: the descriptor goes into the kernel arguments
+        const LiveStream* dsc = reinterpret_cast<const LiveStream*>(lv.h_desc);
+        bool same = true;
+        for (int s = 1; s < lv.S && same; ++s) same = std::memcmp(&dsc[s], &dsc[0], sizeof(LiveStream)) == 0;
+        ls.uniform = same ? 1 : 0;
+        ls.uni = dsc[0];
+    }
+#ifdef EMSPEC_DIAG
+    ls.stamps = lv.stamps;
+#endif
     // with the post-process the frame kernel's columns are raw dB on the device, laid out like the destination
     if (post) {
         if ((size_t)lv.S * out_cols * e->cfg.rows * 4 > lv.raw_bytes &&
@@ -363,6 +378,17 @@ int emspec_push_samples_multi(emspec_engine* e, const float* samples, int32_t st
     }
     return EMSPEC_OK;
 }
+
+#ifdef EMSPEC_DIAG
+// diagnostic build (include/emspec_debug.h): where the live frame kernel stamps its phases - stamps[S][8], page-locked host
+// memory of the caller (NULL: off)
+int emspec_debug_live_stamps(emspec_engine* e, uint64_t* stamps) {
+    if (!e) return EMSPEC_ERR_INVALID_ARG;
+    e->live.stamps = reinterpret_cast<unsigned long long*>(device_view(stamps));
+    if (stamps && !e->live.stamps) return fail(e, EMSPEC_ERR_INVALID_ARG, "stamps must be page-locked host memory");
+    return EMSPEC_OK;
+}
+#endif
 
 int emspec_reset_stream(emspec_engine* e, int32_t stream) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;

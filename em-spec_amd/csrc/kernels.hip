@@ -251,12 +251,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         const float xv = live ? lb.sample(n) : x[n];
         v[i] = make_float2(xv, xv * ((float)(n - N / 2) * rs));
     }
+    if constexpr (live) live_stamp_after(sk.live, s, (int)f, 2, v[15].x + v[0].x);   // (diagnostic build only: waits for the samples)
     // stage "STFT": first pass (stages 0..3) straight from registers
     fft_stages<LOG2N, 0, 4>(v, t, pl.tw);
 #pragma unroll
     for (int i = 0; i < 16; ++i) sm[padi(t) + (T + T / 16) * i] = v[i];   // padi(t + T i) = padi(t) + (T + T/16) i: T is a multiple of 16
     __syncthreads();
     fft_rest<LOG2N, 4>(sm, stw, t, pl.tw);
+    if constexpr (live) live_stamp(sk.live, s, (int)f, 3);
 
     // per-bin stages: k = t + T*i (i = 0..7), plus k = N/2 on thread 0
     HintLookup lk;
@@ -308,7 +310,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         const int bwm = natpos<LOG2N>((1 - t) & (T - 1)) + T * (16 - (t >= 2 ? 1 : 0));
         const int bw0 = natpos<LOG2N>((0 - t) & (T - 1)) + T * (16 - (t >= 1 ? 1 : 0));
         const int bwp = natpos<LOG2N>(T - 1 - t) + T * 15;
-#pragma unroll EMSPEC_BINS_UNROLL
+        // (the live form is latency-bound - one wave per SIMD - and overlaps the bins' LDS round trips instead)
+        constexpr int BU = SINK == 3 ? 7 : EMSPEC_BINS_UNROLL;
+#pragma unroll BU
         for (int i = 1; i < 8; ++i)
             do_bin(t + T * i, bzm + T * i, bz0 + T * i, bzp + T * i, bwm - T * i, bw0 - T * i, bwp - T * i);
     }
@@ -316,6 +320,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
     if constexpr (SINK == 3) {
         if (live_last_arrival(sk.live, s, lb.d.frames, sm))
             live_finalize<float>(sk.live, lb.d, s, sk.hist, (int)sk.hist_slots, pl.rows, pl.D, T, LiveConvF32{sk.fin_map});
+        live_stamp(sk.live, s, (int)f, 6);
         return;
     }
     if constexpr (SINK != 0) return;

@@ -563,6 +563,228 @@ static napi_value BatchPackedAsync(napi_env env, napi_callback_info info) {
     return promise;
 }
 
+/* ---- live multi-stream streaming (emspec_columns / emspec_push_samples_multi): S streams per call, one launch ---- */
+
+/* optional Float64Array(S) that receives int64 values (column indices / counts: exact in a double) */
+static int get_f64_out(napi_env env, napi_value v, size_t want, double** out) {
+    void* d = NULL; size_t len = 0;
+    *out = NULL;
+    if (!get_typed(env, v, napi_float64_array, &d, &len, 1)) return 0;
+    if (d && len != want) return 0;
+    *out = (double*)d;
+    return 1;
+}
+
+/* columns(handle, frames:Float32Array(S*fftSize), S, fftSize, hop, reassign, outDb?:Float32Array(S*rows),
+ *         outRgba?:Uint8Array(4*S*rows), outColumns?:Float64Array(S)) : one frame of each of S streams -> their finished columns */
+static napi_value Columns(napi_env env, napi_callback_info info) {
+    size_t argc = 9; napi_value argv[9];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 6) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "columns(handle, frames, S, fftSize, hop, reassign[, outDb, outRgba, outColumns])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* fr; size_t flen;
+    if (!get_typed(env, argv[1], napi_float32_array, &fr, &flen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "frames must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[5], &argv[5]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[5], &reassign));
+    if (S < 1 || n < 1 || (size_t)S * (size_t)n != flen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "frames.length must equal S*fftSize"); return NULL; }
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0; double* ocol = NULL;
+    if (argc > 6 && !get_typed(env, argv[6], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 7 && !get_typed(env, argv[7], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 8 && !get_f64_out(env, argv[8], (size_t)S, &ocol)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outColumns must be a Float64Array(S)"); return NULL; }
+    const size_t cells = (size_t)S * (size_t)h->rows;
+    if ((db && dblen != cells) || (rgba && rgbalen != 4 * cells)) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must hold S*rows floats, outRgba 4*S*rows bytes (rows = the engine's row count)"); return NULL; }
+    int64_t* c64 = ocol ? (int64_t*)malloc((size_t)S * sizeof(int64_t)) : NULL;
+    if (ocol && !c64) { napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
+    int rc = emspec_columns(h->e, (const float*)fr, S, n, hop, reassign ? 1 : 0, (float*)db, (uint8_t*)rgba, h->rows, c64);
+    if (rc == EMSPEC_OK && ocol) for (int32_t s = 0; s < S; ++s) ocol[s] = (double)c64[s];
+    free(c64);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+/* columnsFlush(handle, outDb?, outRgba?, outColumns?:Float64Array(S)): every stream with pending columns emits its next one */
+static napi_value ColumnsFlush(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "columnsFlush(handle[, outDb, outRgba, outColumns])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    const int32_t S = emspec_live_streams(h->e);
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0; double* ocol = NULL;
+    if (argc > 1 && !get_typed(env, argv[1], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 2 && !get_typed(env, argv[2], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 3 && !get_f64_out(env, argv[3], (size_t)S, &ocol)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outColumns must be a Float64Array(S)"); return NULL; }
+    const size_t cells = (size_t)S * (size_t)h->rows;
+    if ((db && dblen != cells) || (rgba && rgbalen != 4 * cells)) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must hold S*rows floats, outRgba 4*S*rows bytes (S = the live session's streams)"); return NULL; }
+    int64_t* c64 = (ocol && S > 0) ? (int64_t*)malloc((size_t)S * sizeof(int64_t)) : NULL;
+    int rc = emspec_columns_flush(h->e, (float*)db, (uint8_t*)rgba, h->rows, c64);
+    if (rc == EMSPEC_OK && ocol && c64) for (int32_t s = 0; s < S; ++s) ocol[s] = (double)c64[s];
+    free(c64);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+/* pushColumnsMulti(handle, count, fftSize, hop, reassign) -> the largest per-stream column count a block of `count` samples completes */
+static napi_value PushColumnsMulti(napi_env env, napi_callback_info info) {
+    size_t argc = 5; napi_value argv[5];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 5) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pushColumnsMulti(handle, count, fftSize, hop, reassign)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    int64_t count; int32_t n, hop; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[1], &count));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[4], &argv[4]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[4], &reassign));
+    const int64_t k = emspec_push_columns_multi(h->e, count, n, hop, reassign ? 1 : 0);
+    if (k < 0) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "invalid count / fftSize / hop"); return NULL; }
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int64(env, k, &r));
+    return r;
+}
+
+/* pushMulti(handle, samples:Float32Array(S*count), S, fftSize, hop, reassign, maxColumns, outDb?:Float32Array(S*maxColumns*rows),
+ *           outRgba?:Uint8Array(4*S*maxColumns*rows), outCounts?:Float64Array(S), outFirst?:Float64Array(S)) */
+static napi_value PushMulti(napi_env env, napi_callback_info info) {
+    size_t argc = 11; napi_value argv[11];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 7) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "pushMulti(handle, samples, S, fftSize, hop, reassign, maxColumns[, outDb, outRgba, outCounts, outFirst])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* smp; size_t slen;
+    if (!get_typed(env, argv[1], napi_float32_array, &smp, &slen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "samples must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; int64_t maxc; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[5], &argv[5]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[5], &reassign));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int64(env, argv[6], &maxc));
+    if (S < 1 || slen % (size_t)S != 0) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "samples.length must be a multiple of S"); return NULL; }
+    if (maxc < 0) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "maxColumns must be >= 0"); return NULL; }
+    const int64_t count = (int64_t)(slen / (size_t)S);
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0; double *ocnt = NULL, *ofirst = NULL;
+    if (argc > 7 && !get_typed(env, argv[7], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 8 && !get_typed(env, argv[8], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 9 && !get_f64_out(env, argv[9], (size_t)S, &ocnt)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outCounts must be a Float64Array(S)"); return NULL; }
+    if (argc > 10 && !get_f64_out(env, argv[10], (size_t)S, &ofirst)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outFirst must be a Float64Array(S)"); return NULL; }
+    const size_t cells = (size_t)S * (size_t)maxc * (size_t)h->rows;
+    if ((db && dblen != cells) || (rgba && rgbalen != 4 * cells)) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must hold S*maxColumns*rows floats, outRgba 4x that in bytes"); return NULL; }
+    int64_t* tmp = (int64_t*)malloc((size_t)S * 2 * sizeof(int64_t));
+    if (!tmp) { napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
+    int rc = emspec_push_samples_multi(h->e, (const float*)smp, S, count, count, n, hop, reassign ? 1 : 0, (float*)db, (uint8_t*)rgba,
+                                       h->rows, maxc, tmp, tmp + S);
+    if (rc == EMSPEC_OK) for (int32_t s = 0; s < S; ++s) { if (ocnt) ocnt[s] = (double)tmp[s]; if (ofirst) ofirst[s] = (double)tmp[S + s]; }
+    free(tmp);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+static napi_value ResetStream(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 2) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "resetStream(handle, stream)"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    int32_t s;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[1], &s));
+    int rc = emspec_reset_stream(h->e, s);
+    if (rc != EMSPEC_OK) return throw_status(env, h->e, rc);
+    return NULL;
+}
+
+static napi_value LiveStreams(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    napi_value r; NAPI_OK_OR_RETURN(env, napi_create_int32(env, emspec_live_streams(h->e), &r));
+    return r;
+}
+
+/* columnsAsync(handle, frames, S, fftSize, hop, reassign, outDb?, outRgba?, outColumns?) -> Promise<undefined>: columns() on the
+ * libuv thread pool (napi_create_async_work).  The typed arrays are kept alive by references; the caller touches neither them
+ * nor the engine before the promise settles (an engine is not thread-safe). */
+typedef struct {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref refs[4];
+    emspec_engine* e;
+    const float* frames;
+    float* db; uint8_t* rgba; double* ocol; int64_t* c64;
+    int32_t S, n, hop, reassign, rows;
+    int rc;
+    char msg[256];
+} columns_job;
+
+static void columns_execute(napi_env env, void* data) {
+    (void)env;
+    columns_job* j = (columns_job*)data;
+    j->rc = emspec_columns(j->e, j->frames, j->S, j->n, j->hop, j->reassign, j->db, j->rgba, j->rows, j->c64);
+    if (j->rc != EMSPEC_OK) { strncpy(j->msg, emspec_last_error(j->e), sizeof(j->msg) - 1); j->msg[sizeof(j->msg) - 1] = 0; }
+}
+
+static void columns_complete(napi_env env, napi_status status, void* data) {
+    columns_job* j = (columns_job*)data;
+    if (status == napi_ok && j->rc == EMSPEC_OK) {
+        if (j->ocol) for (int32_t s = 0; s < j->S; ++s) j->ocol[s] = (double)j->c64[s];
+        napi_value v; napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value code, msg, err;
+        napi_create_string_utf8(env, status == napi_ok ? status_name(j->rc) : "EMSPEC_NAPI", NAPI_AUTO_LENGTH, &code);
+        napi_create_string_utf8(env, status == napi_ok ? j->msg : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, code, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    for (int i = 0; i < 4; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+    napi_delete_async_work(env, j->work);
+    free(j->c64);
+    free(j);
+}
+
+static napi_value ColumnsAsync(napi_env env, napi_callback_info info) {
+    size_t argc = 9; napi_value argv[9];
+    NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 6) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "columnsAsync(handle, frames, S, fftSize, hop, reassign[, outDb, outRgba, outColumns])"); return NULL; }
+    handle_t* h = get_handle(env, argv[0]); if (!h) return NULL;
+    void* fr; size_t flen;
+    if (!get_typed(env, argv[1], napi_float32_array, &fr, &flen, 0)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "frames must be a Float32Array"); return NULL; }
+    int32_t S, n, hop; bool reassign;
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[2], &S));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[3], &n));
+    NAPI_OK_OR_RETURN(env, napi_get_value_int32(env, argv[4], &hop));
+    NAPI_OK_OR_RETURN(env, napi_coerce_to_bool(env, argv[5], &argv[5]));
+    NAPI_OK_OR_RETURN(env, napi_get_value_bool(env, argv[5], &reassign));
+    if (S < 1 || n < 1 || (size_t)S * (size_t)n != flen) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "frames.length must equal S*fftSize"); return NULL; }
+    void *db = NULL, *rgba = NULL; size_t dblen = 0, rgbalen = 0; double* ocol = NULL;
+    if (argc > 6 && !get_typed(env, argv[6], napi_float32_array, &db, &dblen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must be a Float32Array"); return NULL; }
+    if (argc > 7 && !get_typed(env, argv[7], napi_uint8_array, &rgba, &rgbalen, 1)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outRgba must be a Uint8Array"); return NULL; }
+    if (argc > 8 && !get_f64_out(env, argv[8], (size_t)S, &ocol)) { napi_throw_type_error(env, "EMSPEC_ERR_INVALID_ARG", "outColumns must be a Float64Array(S)"); return NULL; }
+    const size_t cells = (size_t)S * (size_t)h->rows;
+    if ((db && dblen != cells) || (rgba && rgbalen != 4 * cells)) { napi_throw_error(env, "EMSPEC_ERR_INVALID_ARG", "outDb must hold S*rows floats, outRgba 4*S*rows bytes (rows = the engine's row count)"); return NULL; }
+    columns_job* j = (columns_job*)calloc(1, sizeof(columns_job));
+    if (!j) { napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "calloc"); return NULL; }
+    j->c64 = (int64_t*)malloc((size_t)S * sizeof(int64_t));
+    if (!j->c64) { free(j); napi_throw_error(env, "EMSPEC_ERR_OUT_OF_MEMORY", "malloc"); return NULL; }
+    j->e = h->e; j->frames = (const float*)fr; j->db = (float*)db; j->rgba = (uint8_t*)rgba; j->ocol = ocol;
+    j->S = S; j->n = n; j->hop = hop; j->reassign = reassign ? 1 : 0; j->rows = h->rows;
+    napi_value promise, name;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok) { free(j->c64); free(j); napi_throw_error(env, "EMSPEC_NAPI", "napi_create_promise"); return NULL; }
+    napi_create_reference(env, argv[1], 1, &j->refs[0]);
+    if (db) napi_create_reference(env, argv[6], 1, &j->refs[1]);
+    if (rgba) napi_create_reference(env, argv[7], 1, &j->refs[2]);
+    if (ocol) napi_create_reference(env, argv[8], 1, &j->refs[3]);
+    napi_create_string_utf8(env, "emspec.columnsAsync", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, columns_execute, columns_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        for (int i = 0; i < 4; ++i) if (j->refs[i]) napi_delete_reference(env, j->refs[i]);
+        free(j->c64); free(j);
+        napi_throw_error(env, "EMSPEC_NAPI", "could not queue async work");
+        return NULL;
+    }
+    return promise;
+}
+
 static napi_value SetColormap(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
     NAPI_OK_OR_RETURN(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
@@ -765,6 +987,13 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"batchGather", NULL, BatchGather, NULL, NULL, NULL, napi_default, NULL},
         {"buildInfo", NULL, BuildInfo, NULL, NULL, NULL, napi_default, NULL},
         {"deviceStatus", NULL, DeviceStatus, NULL, NULL, NULL, napi_default, NULL},
+        {"columns", NULL, Columns, NULL, NULL, NULL, napi_default, NULL},
+        {"columnsAsync", NULL, ColumnsAsync, NULL, NULL, NULL, napi_default, NULL},
+        {"columnsFlush", NULL, ColumnsFlush, NULL, NULL, NULL, napi_default, NULL},
+        {"pushMulti", NULL, PushMulti, NULL, NULL, NULL, napi_default, NULL},
+        {"pushColumnsMulti", NULL, PushColumnsMulti, NULL, NULL, NULL, napi_default, NULL},
+        {"resetStream", NULL, ResetStream, NULL, NULL, NULL, napi_default, NULL},
+        {"liveStreams", NULL, LiveStreams, NULL, NULL, NULL, napi_default, NULL},
     };
     napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
     return exports;

@@ -14,13 +14,87 @@
 const native = require('./emspec.node');
 
 class Engine {
-  /** config: {device, rows, sampleRate, fminHz, fmaxHz, gain, dbTop, dbRange, gateDb, powerFloor, exact}
-   *  exact: true = EMSPEC_MODE_EXACT (binary64 arithmetic, 64-bit fixed-point histogram; include/emspec.h) */
+  /** config: {device, rows, sampleRate, fminHz, fmaxHz, gain, dbTop, dbRange, gateDb, powerFloor, exact, streams}
+   *  exact: true = EMSPEC_MODE_EXACT (binary64 arithmetic, 64-bit fixed-point histogram; include/emspec.h)
+   *  streams: S > 1 = a live multi-stream engine: computeSpectrogramColumns / pushSamplesMulti advance all S streams per
+   *  call in ONE kernel launch; its frame / column blocks are page-locked (engine.frames, engine.columnsDb, ...), so the
+   *  kernel reads and writes them in place */
   constructor(config = {}) {
     this.rows = native.rows(config);
     this._h = native.create(config);
     this._db = new Float32Array(this.rows);
+    this.streams = Math.max(1, config.streams | 0);
+    this.columnIndex = new Float64Array(this.streams);   // per stream: index of the column the last call returned (-1: empty)
   }
+
+  /** Page-locked Float32Array / Uint8Array views for the live calls, (re)made when the shape changes. */
+  _liveBlocks(fftSize, wantRgba) {
+    const S = this.streams, R = this.rows;
+    if (!this.frames || this.frames.length !== S * fftSize) this.frames = new Float32Array(native.allocPinned(4 * S * fftSize));
+    if (!this.columnsDb) this.columnsDb = new Float32Array(native.allocPinned(4 * S * R));
+    if (wantRgba && !this.columnsRgba) this.columnsRgba = new Uint8Array(native.allocPinned(4 * S * R));
+  }
+
+  /**
+   * The live multi-stream form of computeSpectrogramColumn: one frame of each of the engine's S streams in, one finished
+   * column of each out, ONE launch (emspec_columns).  frames: Float32Array(S * fftSize), stream after stream - pass
+   * engine.frames (page-locked, filled by the caller) to avoid a staging copy; any Float32Array works.
+   * Returns engine.columnsDb: Float32Array(S * rows) of dB (page-locked, overwritten by the next call); with wantRgba,
+   * engine.columnsRgba holds the colours.  engine.columnIndex[s] = index of stream s's column, -1 while its ring primes.
+   */
+  computeSpectrogramColumns(frames, fftSize, hop, reassign = true, wantRgba = false) {
+    this._liveBlocks(fftSize, wantRgba);
+    native.columns(this._h, frames, this.streams, fftSize, hop, !!reassign, this.columnsDb, wantRgba ? this.columnsRgba : undefined,
+      this.columnIndex);
+    return this.columnsDb;
+  }
+
+  /** computeSpectrogramColumns off the JS thread (libuv pool): resolves with engine.columnsDb.  Do not touch the blocks or
+   *  this engine until the promise settles. */
+  computeSpectrogramColumnsAsync(frames, fftSize, hop, reassign = true, wantRgba = false) {
+    this._liveBlocks(fftSize, wantRgba);
+    return native.columnsAsync(this._h, frames, this.streams, fftSize, hop, !!reassign, this.columnsDb,
+      wantRgba ? this.columnsRgba : undefined, this.columnIndex).then(() => this.columnsDb);
+  }
+
+  /** Every stream that still has pending columns emits its next one (others: the empty column, columnIndex -1);
+   *  throws EMSPEC_ERR_STATE when no stream has any.  Returns engine.columnsDb. */
+  flushColumns(wantRgba = false) {
+    this._liveBlocks(this.frames ? this.frames.length / this.streams : 0, wantRgba);
+    native.columnsFlush(this._h, this.columnsDb, wantRgba ? this.columnsRgba : undefined, this.columnIndex);
+    return this.columnsDb;
+  }
+
+  /**
+   * Live streaming by sample blocks for all S streams (emspec_push_samples_multi): samples = Float32Array(S * count),
+   * `count` new samples of every stream, stream after stream (engine.sampleBlock(count) is a page-locked one).
+   * Returns { maxColumns, counts, first, db, rgba }: stream s completed counts[s] columns,
+   * db.subarray((s * maxColumns + i) * rows, ...) is its i-th, first[s] the absolute index of its first (-1 if none).
+   * db / rgba / counts / first are engine-owned page-locked blocks, overwritten by the next call (copy what you keep).
+   * Drain the pending columns with flushColumns().
+   */
+  pushSamplesMulti(samples, fftSize, hop, reassign = true, wantRgba = false) {
+    const S = this.streams, count = samples.length / S;
+    const maxColumns = native.pushColumnsMulti(this._h, count, fftSize, hop, !!reassign);
+    let o = this._push;
+    if (!o || o.maxColumns < maxColumns || (wantRgba && !o.rgbaAll)) {
+      const cap = Math.max(maxColumns, 1);
+      o = this._push = { maxColumns: cap, dbAll: new Float32Array(native.allocPinned(4 * S * cap * this.rows)),
+        rgbaAll: wantRgba ? new Uint8Array(native.allocPinned(4 * S * cap * this.rows)) : undefined,
+        counts: new Float64Array(S), first: new Float64Array(S) };
+    }
+    native.pushMulti(this._h, samples, S, fftSize, hop, !!reassign, o.maxColumns, o.dbAll, wantRgba ? o.rgbaAll : undefined, o.counts, o.first);
+    return { maxColumns: o.maxColumns, counts: o.counts, first: o.first, db: o.dbAll, rgba: wantRgba ? o.rgbaAll : undefined };
+  }
+
+  /** A page-locked Float32Array(S * count) for pushSamplesMulti (kept per count). */
+  sampleBlock(count) {
+    if (!this._blk || this._blk.length !== this.streams * count) this._blk = new Float32Array(native.allocPinned(4 * this.streams * count));
+    return this._blk;
+  }
+
+  /** Restart stream s of the live session (its position, pending columns, display state); the others continue. */
+  resetStream(s) { native.resetStream(this._h, s); }
 
   /**
    * One frame in, one finished column out.  With time reassignment on, the column
@@ -155,6 +229,18 @@ const colormapStops = {
 };
 
 let defaultEngine = null;
+let defaultMulti = null;
+
+/** Drop-in for a renderer that draws S streams: frames = Float32Array(S * fftSize) -> Float32Array(S * rows) of dB
+ *  (one launch for all streams).  Lazily creates one engine per stream count. */
+function computeSpectrogramColumns(frames, fftSize, hop, reassign = true) {
+  const S = frames.length / fftSize;
+  if (!defaultMulti || defaultMulti.streams !== S) {
+    if (defaultMulti) defaultMulti.destroy();
+    defaultMulti = new Engine({ streams: S });
+  }
+  return defaultMulti.computeSpectrogramColumns(frames, fftSize, hop, reassign);
+}
 
 /** Drop-in for the renderer: lazily creates one engine with the default configuration. */
 function computeSpectrogramColumn(audioFrame, fftSize, hop, reassign = true) {
@@ -166,6 +252,7 @@ module.exports = {
   Engine,
   createEngine: (config) => new Engine(config),
   computeSpectrogramColumn,
+  computeSpectrogramColumns,
   /** ArrayBuffer of page-locked host memory: typed arrays over it move at full PCIe speed. */
   allocPinned: native.allocPinned,
   warpedEdges,

@@ -246,6 +246,81 @@ async function checkAsync() {
   eng.destroy();
 }
 
+/* Live multi-stream engine ({streams: S}): computeSpectrogramColumns (one frame of every stream per call, one launch),
+ * flushColumns, pushSamplesMulti, resetStream and the async-work form.  EXACT mode: every stream's columns must equal the
+ * batched call's float32 bits; stream 0 is also held against the plain-JS float64 method (8.7e-4 dB on strong cells). */
+async function checkLive() {
+  const S = 6, fftSize = 4096, hop = 256, frames = 64, L = fftSize + hop * (frames - 1);
+  const eng = em.createEngine({ exact: true, streams: S });
+  const R = eng.rows, D = em.latencyColumns(fftSize, hop, true);
+  const pcm = new Float32Array(S * L);
+  const base = synth(L);
+  for (let s = 0; s < S; s++) pcm.set(base.map((v, i) => v * (1 - 0.12 * s) * ((i + 3 * s) % 7 ? 1 : 0.6)), s * L);
+  const batch = new Float32Array(S * frames * R);
+  const one = em.createEngine({ exact: true });
+  one.computeColumns(pcm, S, L, fftSize, hop, true, { db: batch });
+  one.destroy();
+  const got = new Float32Array(S * frames * R);
+  const take = (db) => {
+    for (let s = 0; s < S; s++) if (eng.columnIndex[s] >= 0) got.set(db.subarray(s * R, (s + 1) * R), (s * frames + eng.columnIndex[s]) * R);
+  };
+  eng._liveBlocks(fftSize, false);
+  for (let j = 0; j < frames; j++) {
+    for (let s = 0; s < S; s++) eng.frames.set(pcm.subarray(s * L + j * hop, s * L + j * hop + fftSize), s * fftSize);
+    // alternate the synchronous and the async-work form
+    const db = (j & 1) ? await eng.computeSpectrogramColumnsAsync(eng.frames, fftSize, hop, true) : eng.computeSpectrogramColumns(eng.frames, fftSize, hop, true);
+    for (let s = 0; s < S; s++) if (eng.columnIndex[s] !== (j >= D ? j - D : -1)) throw new Error('live: column index of stream ' + s + ' at call ' + j);
+    take(db);
+  }
+  for (let k = 0; k < D; k++) take(eng.flushColumns());
+  let threw = false;
+  try { eng.flushColumns(); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
+  if (!threw) throw new Error('live: flush past the end must throw EMSPEC_ERR_STATE');
+  for (let i = 0; i < got.length; i++) if (got[i] !== batch[i]) throw new Error('live exact columns differ from the batch at cell ' + i);
+  const want = ref.columnsDb(pcm.subarray(0, L), fftSize, hop, true, frames);
+  let strong = 0, worst = 0;
+  for (let i = 0; i < want.length; i++) if (want[i] > -60) { strong++; worst = Math.max(worst, Math.abs(got[i] - want[i])); }
+  if (!(strong > 100 && worst < 8.7e-4)) throw new Error('live vs plain-JS float64 oracle: ' + strong + ' strong cells, worst ' + worst + ' dB');
+  // sample blocks: a hop per call for every stream, stream 2 restarted half way on stream 0's audio
+  eng.reset();
+  const got2 = new Float32Array(S * frames * R);
+  const cut = fftSize + hop * 19;                      // samples fed when the restart happens (frame 19 complete)
+  let fed = 0;
+  const blk = new Float32Array(S * hop);
+  const newCols = [];
+  while (fed < L) {
+    const cnt = Math.min(hop, L - fed);
+    if (fed === cut) eng.resetStream(2);
+    const b = cnt === hop ? blk : new Float32Array(S * cnt);
+    for (let s = 0; s < S; s++) {
+      const src = (s === 2 && fed >= cut) ? pcm.subarray(fed - cut, fed - cut + cnt) : pcm.subarray(s * L + fed, s * L + fed + cnt);
+      b.set(src, s * cnt);
+    }
+    const r = eng.pushSamplesMulti(b, fftSize, hop, true);
+    for (let s = 0; s < S; s++) for (let i = 0; i < r.counts[s]; i++) {
+      const colv = r.db.subarray((s * r.maxColumns + i) * R, (s * r.maxColumns + i + 1) * R);
+      if (s === 2 && fed >= cut) newCols.push(Float32Array.from(colv));
+      else got2.set(colv, (s * frames + r.first[s] + i) * R);
+    }
+    fed += cnt;
+  }
+  for (let s = 0; s < S; s++) {
+    const upto = (s === 2 ? 20 : frames) - D;          // complete columns before the restart / before the flush
+    for (let i = 0; i < upto * R; i++) if (got2[s * frames * R + i] !== batch[s * frames * R + i]) throw new Error('live push: stream ' + s + ' differs at ' + i);
+  }
+  if (newCols.length < 8) throw new Error('live push: restarted stream produced ' + newCols.length + ' columns');
+  for (let c = 0; c < newCols.length; c++) for (let r = 0; r < R; r++)
+    if (newCols[c][r] !== batch[c * R + r]) throw new Error('live push: restarted stream column ' + c + ' differs from stream 0');
+  threw = false;
+  try { eng.computeSpectrogramColumns(eng.frames, fftSize, hop, true); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
+  if (!threw) throw new Error('live: mixing frame and sample feeding must throw EMSPEC_ERR_STATE');
+  eng.destroy();
+  // module-level drop-in
+  const cols = em.computeSpectrogramColumns(new Float32Array(3 * 1024), 1024, 256, false);
+  if (cols.length !== 3 * 1024) throw new Error('module-level multi-stream call');
+  return worst;
+}
+
 checkAgainstJsOracle(1024, 256, false, 40);
 checkAgainstJsOracle(4096, 256, true, 48);
 const wx = checkExactAgainstJsOracle(4096, 256, 48);
@@ -258,6 +333,6 @@ checkPush(4096, 256, true, 150);
 checkPush(1024, 256, false, 90);
 const col = em.computeSpectrogramColumn(new Float32Array(1024), 1024, 256, false);
 if (col.length !== 1024) throw new Error('module-level call');
-checkAsync().then(() => {
-  console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2), '; exact mode vs plain-JS float64, worst strong cell', wx.toExponential(2), 'dB');
+checkAsync().then(checkLive).then((wl) => {
+  console.log('node addon ok: max |dB| diff streaming vs batch', w1.toExponential(2), w2.toExponential(2), '; exact mode vs plain-JS float64, worst strong cell', wx.toExponential(2), 'dB; live multi-stream (6 streams, exact) == batch bytes, vs float64', wl.toExponential(2), 'dB');
 }).catch((e) => { console.error(e); process.exit(1); });

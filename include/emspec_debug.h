@@ -43,6 +43,11 @@ int emspec_debug_fused_error(emspec_engine* e);
  * units while the column kernels run on another stream (tools/occupancy_probe.py). */
 int emspec_debug_occupy(emspec_engine* e, int32_t groups, int32_t usec, void* hip_stream);
 
+/* Live multi-stream calls: have the frame kernel's first workgroup of every stream stamp the 100 MHz wall clock at its
+ * phases into stamps[streams][8] (page-locked host memory of the caller; NULL = off): 0 entry, 1 descriptor read, 2 samples
+ * in registers, 3 transform done, 4 bins + scatter issued, 5 ticket taken, 6 finalised (tools/live_phases.py). */
+int emspec_debug_live_stamps(emspec_engine* e, uint64_t* stamps);
+
 #ifdef __cplusplus
 }
 #endif

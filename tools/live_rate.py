@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-call host time of the live multi-stream entry points (emspec_columns / emspec_push_samples_multi) on the GPU box:
 S streams x one hop per call, N = 4096 / hop 256 (BASELINE configs[2] in its live form).  Prints one line per variant:
-median / p90 microseconds per call and columns/s.  usage: live_rate.py [S] [calls]"""
+median / p90 microseconds per call and columns/s.  usage: live_rate.py [S] [calls] [filter,filter,...]
+(filters: every token must appear in the variant's label, e.g. FAST,samples,pinned,out=db)"""
 import os
 import sys
 import time
@@ -27,6 +28,7 @@ def timed(fn, calls):
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else []
     n, hop, R = 4096, 256, 1024
     L = n + hop * (calls + 4)
     pcm = synth.streams(min(S, 8), L)
@@ -35,6 +37,9 @@ def main():
         for pinned in (True, False):
             for form in ("samples", "frames"):
                 for outs in (("db",), ("rgba",), ("db", "rgba")):
+                    label = f"{mname:5s} S={S:3d} {form:7s} {'pinned' if pinned else 'pageable':8s} out={'+'.join(outs):7s} "
+                    if not all(tok in label + " " for tok in only):
+                        continue
                     with emspec.Engine(mode=mode) as e:
                         keep = []
                         def buf(shape, dt):
@@ -74,7 +79,7 @@ def main():
                                 ts[i] = time.perf_counter() - t0
                             ts = ts[calls // 10:]
                         med, p90 = np.median(ts) * 1e6, np.percentile(ts, 90) * 1e6
-                        print(f"{mname:5s} S={S:3d} {form:7s} {'pinned' if pinned else 'pageable':8s} out={'+'.join(outs):7s} "
+                        print(f"{label}"
                               f"median {med:7.1f} us  p90 {p90:7.1f} us  -> {S / (med * 1e-6):.3e} columns/s", flush=True)
                         for p in keep:
                             p.close()
