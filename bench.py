@@ -280,7 +280,9 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
                                  "rates measured here on the same pinned buffers, one direction at a time; duplex_GBps = what each "
                                  "direction reaches when two plain hipMemcpyAsync run against each other (frac_of_duplex: against that)",
                          "h2d_GBps": h2d, "d2h_GBps": d2h}}
-        wire = pix.array.reshape(-1)
+        # (the images of S streams always fit S * emspec_wire_bound; a dense input would not fit the index block's S*C*R bytes)
+        pwire = emspec.PinnedArray((S * emspec.wire_bound(Cn, R),), np.uint8)
+        wire = pwire.array
         offs = np.zeros(S + 1, np.int64)
         dt = timed(lambda: eng._chk(lib.emspec_batch_packed(eng._h, C_.c_void_p(pin.array.ctypes.data), S, L, n, hop, 1, C_.c_void_p(wire.ctypes.data),
                                                             C_.c_int64(wire.size), offs.ctypes.data_as(C_.c_void_p))))
@@ -297,6 +299,110 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
     finally:
         pin.close()
         pix.close()
+        if "pwire" in locals():
+            pwire.close()
+    return out
+
+
+def live_configs(dev_index, pcm_dev, n, hop, R, calls=1500):
+    """The LIVE form of configs[2] (north_star: the per-frame computeSpectrogramColumn the renderer calls; README.md:36): S
+    streams advance by one hop per call, ONE launch + ONE synchronisation (emspec_push_samples_multi: hop new samples per
+    stream in, one finished dB column per stream out; emspec_columns: a whole frame per stream in), page-locked buffers read
+    and written by the kernel in place.  What is timed is the call as the host thread sees it (wall clock around the C-ABI
+    call with prebuilt ctypes arguments; filling the sample block is the audio callback's copy and not timed)."""
+    import ctypes as C_
+    import emspec
+    lib = emspec.load()
+    S = int(pcm_dev.shape[0])
+    need = n + hop * (calls + 2)
+    host = pcm_dev[:, :need].cpu().numpy()
+    D_ = emspec.latency_columns(n, hop, True)
+    out = {}
+    for mode, mname in ((emspec.MODE_FAST, ""), (emspec.MODE_EXACT, "EXACT mode, ")):
+        blk = emspec.PinnedArray((S, hop), np.float32)
+        frm = emspec.PinnedArray((S, n), np.float32)
+        odb = emspec.PinnedArray((S, 1, R), np.float32)
+        cnt, first = np.zeros(S, np.int64), np.zeros(S, np.int64)
+        try:
+            with emspec.Engine(device=dev_index, mode=mode) as e:
+                e.push_samples_multi(host[:, :n - hop].copy(), n, hop, True, want_db=False)      # prime: no frame complete yet
+                args = (e._h, C_.c_void_p(blk.array.ctypes.data), C_.c_int32(S), C_.c_int64(hop), C_.c_int64(hop), C_.c_int32(n),
+                        C_.c_int32(hop), C_.c_int32(1), C_.c_void_p(odb.array.ctypes.data), None, C_.c_int32(R), C_.c_int64(1),
+                        C_.c_void_p(cnt.ctypes.data), C_.c_void_p(first.ctypes.data))
+                ts = np.empty(calls)
+                for i in range(calls):
+                    blk.array[:] = host[:, n - hop + i * hop:n + i * hop]
+                    t0 = time.perf_counter()
+                    rc = lib.emspec_push_samples_multi(*args)
+                    ts[i] = time.perf_counter() - t0
+                    assert rc == 0 and cnt[0] == (1 if i >= D_ else 0), (rc, i, cnt[0])
+                ts = ts[calls // 10:]
+                med = float(np.median(ts))
+                out[f"{mname}live: {S} streams, one hop per call (emspec_push_samples_multi, page-locked blocks), FFT {n}, hop {hop}, reassignment ON"] = {
+                    "columns_per_s": S / med, "us_per_call": med * 1e6, "p90_us_per_call": float(np.percentile(ts, 90)) * 1e6,
+                    "calls": int(ts.size), "streams": S,
+                    "note": "one kernel launch + one stream synchronisation per call; the kernel reads the new samples from and writes "
+                            "the finished dB columns to page-locked host memory (no copy engine); host time of the C-ABI call, wall clock"}
+                e.reset()
+                cols = np.zeros(S, np.int64)
+                args = (e._h, C_.c_void_p(frm.array.ctypes.data), C_.c_int32(S), C_.c_int32(n), C_.c_int32(hop), C_.c_int32(1),
+                        C_.c_void_p(odb.array.ctypes.data), None, C_.c_int32(R), C_.c_void_p(cols.ctypes.data))
+                ts = np.empty(calls)
+                for i in range(calls):
+                    frm.array[:] = host[:, i * hop:i * hop + n]
+                    t0 = time.perf_counter()
+                    rc = lib.emspec_columns(*args)
+                    ts[i] = time.perf_counter() - t0
+                    assert rc == 0
+                ts = ts[calls // 10:]
+                med = float(np.median(ts))
+                out[f"{mname}live: {S} streams, one frame per call (emspec_columns = {S} x computeSpectrogramColumn, page-locked blocks), FFT {n}, hop {hop}, reassignment ON"] = {
+                    "columns_per_s": S / med, "us_per_call": med * 1e6, "p90_us_per_call": float(np.percentile(ts, 90)) * 1e6,
+                    "calls": int(ts.size), "streams": S,
+                    "note": f"{S * n * 4} B of frames per call read by the kernel over PCIe"}
+        finally:
+            for p_ in (blk, frm, odb):
+                p_.close()
+    return out
+
+
+def node_host_configs(pcm_dev, L, n, hop, runs=5):
+    """The same host-buffer and live entries driven from Node through the N-API addon (north_star: "host code stays in
+    JavaScript/Node calling HIP through a thin C-ABI N-API addon"): em-spec_amd/js/bench_emspec.js on the SAME synthetic
+    batch (handed over as a file in /dev/shm), page-locked buffers from allocPinned."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    js = os.path.join(ROOT, "em-spec_amd", "js")
+    if node is None or not os.path.exists(os.path.join(js, "emspec.node")):
+        return {"node host": {"error": "node or the built addon is not available on this box"}}
+    S = int(pcm_dev.shape[0])
+    path = f"/dev/shm/emspec_bench_pcm_{os.getpid()}.f32"
+    try:
+        pcm_dev.cpu().numpy().tofile(path)
+        r = subprocess.run([node, os.path.join(js, "bench_emspec.js"), path, str(S), str(L), str(n), str(hop), str(runs), "1500"],
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"node host": {"error": (r.stderr or r.stdout)[-400:]}}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    out = {}
+    for key, mname in (("fast", ""), ("exact", "EXACT mode, ")):
+        k = d[key]
+        base = f"node host (pinned, {d['node']}): {mname}{S} streams, FFT {n}, hop {hop}, reassignment ON"
+        out[f"{base}, uint8 palette index out (computeColumnsAsync)"] = {
+            "columns_per_s": k["index_out"]["columns_per_s"], "ms": k["index_out"]["ms"], "runs_ms": k["index_out"]["runs"]}
+        out[f"{base}, packed wire images out (computeColumnsPackedAsync)"] = {
+            "columns_per_s": k["packed"]["columns_per_s"], "ms": k["packed"]["ms"], "runs_ms": k["packed"]["runs"],
+            "wire_bytes_per_column": k["packed"]["wire_bytes_per_column"]}
+        out[f"{base}, live: one hop per call (pushSamplesMulti)"] = {
+            "columns_per_s": k["live_push"]["columns_per_s"], "us_per_call": k["live_push"]["us_per_call"],
+            "p90_us_per_call": k["live_push"]["p90_us"], "calls": k["live_push"]["calls"]}
+        out[f"{base}, live: one frame per call (computeSpectrogramColumns)"] = {
+            "columns_per_s": k["live_frames"]["columns_per_s"], "us_per_call": k["live_frames"]["us_per_call"],
+            "p90_us_per_call": k["live_frames"]["p90_us"], "calls": k["live_frames"]["calls"]}
     return out
 
 
@@ -411,6 +517,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     if args.dry_run_ranks:
         # TEST HOOK: the N > 1 start-up without a GPU - rendezvous, one reduction, rank 0's single line
+        if rank == args.hang_rank and args.hang_at_step == 0:
+            raise RuntimeError(f"injected failure of rank {rank} before the rendezvous")
         import torch.distributed as dist
         dist.init_process_group("gloo")
         seen = torch.zeros(world, dtype=torch.int64)
@@ -666,17 +774,13 @@ def main():
         warm.run(2, deadline_s=300.0)   # (connections open here: generous, but a peer that never joins must not hang the job)
         del warm
         # heaviest root first (equal shards), lightest last: if the budget runs out, what was measured includes the default
-        for other in sorted({S, S + S // 32, S + S // 16, S + 3 * S // 32, S + S // 8}):
-            root_count = total_streams - (world - 1) * other
-            if root_count < max(1, args.chunks):
-                continue
+        for trial in shard.trial_splits(world, total_streams, args.chunks):
             # every rank must take the same decision: rank 0's clock decides, the flag is max-reduced
             over = torch.tensor([1.0 if (time.perf_counter() - t_trials) > args.trial_budget_s else 0.0], dtype=torch.float64, device=gdev)
             dist.all_reduce(over, op=dist.ReduceOp.MAX)
             if float(over.item()) > 0:
                 split_trials.append({"streams_per_rank": None, "skipped": f"trial budget of {args.trial_budget_s:.0f} s spent"})
                 break
-            trial = shard.root_light_counts(world, total_streams, 0, root_count)
             job = Job(trial)
             job.run(1, deadline_s=120.0)                   # the first gather of a run opens RCCL's connections
             el = job.run(3, deadline_s=120.0)
@@ -925,6 +1029,16 @@ def main():
                 cfgs.update(host_buffer_configs(eng, pcm, L, n, hop, R))
             except Exception as ex:            # never lose the line over the side measurement
                 cfgs["host buffers"] = {"error": repr(ex)}
+            # ---- configs[2] in its LIVE form: 64 streams, one hop (or one frame) per call, one launch
+            try:
+                cfgs.update(live_configs(dev_index, pcm, n, hop, R))
+            except Exception as ex:
+                cfgs["live"] = {"error": repr(ex)}
+            # ---- the same entries driven from Node through the N-API addon
+            try:
+                cfgs.update(node_host_configs(pcm, L, n, hop))
+            except Exception as ex:
+                cfgs["node host"] = {"error": repr(ex)}
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
 
@@ -981,13 +1095,39 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT a HIP call (the relay parent of an N > 1 job must not hold a GPU context
+    while its ranks run): the KFD topology's nodes with SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES.  Falls back to torch.cuda.device_count() where the topology is not readable."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    count = 0
+    try:
+        for f in nodes:
+            for ln in open(f):
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    count += 1
+                    break
+    except OSError:
+        nodes = []
+    if not nodes:
+        return torch.cuda.device_count()
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            count = min(count, len([x for x in v.split(",") if x.strip() != ""]))
+    return count
+
+
 def spawn_ranks(argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset: the driver's own command form):
     start the N ranks as a CHILD process - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port <free> bench.py <same arguments>` - relay rank 0's single JSON line to stdout, everything else
     to stderr, and return the child's exit code.  Returns None when there is nothing to spawn (N = 1, or already a rank of
-    an external launcher).  This parent makes NO GPU call (argument parsing and torch.cuda.device_count() only, which does
-    not initialise HIP on this image) and never execs: the ranks are children (rccl.h:220 ncclCommInitRank runs in them)."""
+    an external launcher).  This parent makes NO GPU call (argument parsing and a device count read from the KFD topology in
+    sysfs: visible_gpus()) and never execs: the ranks are children (rccl.h:220 ncclCommInitRank runs in them).  A job that
+    fails before rank 0 printed its line leaves ONE JSON error line on stdout (exit code, the last 2 KB of the ranks' stderr)."""
     import signal
     import subprocess
     pre = argparse.ArgumentParser(add_help=False)
@@ -998,7 +1138,7 @@ def spawn_ranks(argv):
     if known.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return None
     if known.backend == "nccl" and not known.dry_run_ranks:
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         if have < known.gpus:          # RCCL refuses two ranks on one device: say so in a line the driver can parse
             print(json.dumps({"error": f"--gpus {known.gpus} with --backend nccl needs {known.gpus} visible GPUs, found {have}",
                               "n_gpus": known.gpus, "visible_gpus": have, "metric": None, "value": None}), flush=True)
@@ -1010,7 +1150,25 @@ def spawn_ranks(argv):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     sys.stderr.write("[bench] starting %d ranks: %s\n" % (known.gpus, " ".join(cmd)))
     sys.stderr.flush()
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True, bufsize=1)
+    # the ranks' stderr is relayed as it comes; its last 2 KB are kept for the error line of a failed job
+    import collections
+    import threading
+    tail = collections.deque()
+    tail_len = [0]
+    rank_errors = []                   # the ranks' own one-line records ({"rank": r, "error": ...}), at most 16
+
+    def relay_stderr():
+        for ln in child.stderr:
+            sys.stderr.write(ln)
+            if ln.startswith('{"rank"') and len(rank_errors) < 16:
+                rank_errors.append(ln.strip()[:600])
+            tail.append(ln)
+            tail_len[0] += len(ln)
+            while tail_len[0] > 2048 and len(tail) > 1:
+                tail_len[0] -= len(tail.popleft())
+    relay = threading.Thread(target=relay_stderr, daemon=True)
+    relay.start()
 
     def forward(signum, _frame):       # the driver's timeout must reach the ranks, not only this relay
         try:
@@ -1028,10 +1186,16 @@ def spawn_ranks(argv):
         else:
             sys.stderr.write(ln)
     rc = child.wait()
+    relay.join(timeout=10.0)
     if rc == 0 and lines != 1:
         sys.stderr.write(f"[bench] the ranks exited 0 but printed {lines} JSON lines\n")
         rc = 1
-    return rc if rc >= 0 else 128 - rc
+    rc = rc if rc >= 0 else 128 - rc
+    if rc != 0 and lines == 0:
+        # a failed N > 1 run still leaves ONE parseable line: what failed, on how many ranks, and the end of their output
+        print(json.dumps({"error": f"the {known.gpus}-rank job failed (exit code {rc})", "n_gpus": known.gpus, "rc": rc,
+                          "metric": None, "value": None, "rank_errors": rank_errors, "stderr_tail": "".join(tail)[-2048:]}), flush=True)
+    return rc
 
 
 if __name__ == "__main__":
@@ -1042,8 +1206,9 @@ if __name__ == "__main__":
         main()
     except SystemExit:
         raise
-    except BaseException:      # any rank's failure ends the job with a non-zero exit (the launcher then stops the others)
+    except BaseException as _ex:      # any rank's failure ends the job with a non-zero exit (the launcher then stops the others)
         import traceback
+        sys.stderr.write(json.dumps({"rank": int(os.environ.get("RANK", "0")), "error": repr(_ex)[:500]}) + "\n")
         traceback.print_exc()
         sys.stderr.flush()
         os._exit(1)

@@ -37,6 +37,40 @@ def root_light_counts(world, total_streams, root, root_count):
     return counts
 
 
+def trial_splits(world, total_streams, chunks):
+    """The stream splits bench.py times at N > 1 (three steps each, the fastest is kept), heaviest root first: equal shards,
+    then the other ranks 1/32, 1/16, 3/32 and 1/8 heavier than an equal share, the root taking what is left (it also
+    receives every other rank's columns).  A split that would leave the root fewer streams than the step has chunks is
+    left out.  512 streams on 8 ranks: roots of 64, 50, 36, 22 and 8 streams."""
+    S = total_streams // world
+    out = []
+    for other in sorted({S, S + S // 32, S + S // 16, S + 3 * S // 32, S + S // 8}):
+        root_count = total_streams - (world - 1) * other
+        if root_count < max(1, chunks):
+            continue
+        out.append(root_light_counts(world, total_streams, 0, root_count))
+    return out
+
+
+def job_device_bytes(counts, rank, L, C, R, nbuf, nch, packed, wire_bound, root=0):
+    """Device memory one rank's job holds for shard sizes `counts` (bench.py's Job): the samples, the float32 dB columns,
+    nbuf palette-index buffers and, on the root, the gather's destination - per chunk either the ranks' expanded blocks or
+    (packed) a directory + every rank's wire image at its bound (wire_bound(columns, rows) -> bytes).  The CPU tests hold the
+    world-8 plans to a stated budget; the MI355X has 288 GB."""
+    Sl = counts[rank]
+    total = Sl * L * 4 + Sl * C * R * 4 + nbuf * Sl * C * R
+    if rank == root and len(counts) > 1:
+        world = len(counts)
+        chunk = lambda Sx: [(Sx * i // nch, Sx * (i + 1) // nch) for i in range(nch)]
+        per_rank = [chunk(c) for c in counts]
+        for ci in range(nch):
+            if packed:
+                total += 256 * (world + 1) + sum(wire_bound((pr[ci][1] - pr[ci][0]) * C, R) for pr in per_rank)
+            else:
+                total += sum(pr[ci][1] - pr[ci][0] for pr in per_rank) * C * R
+    return total
+
+
 def first_streams(counts):
     """Index of each rank's first stream for shard sizes `counts`."""
     out, acc = [], 0

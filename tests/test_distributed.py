@@ -158,3 +158,55 @@ def test_plain_bench_invocation_refuses_more_ranks_than_gpus():
     assert r.returncode != 0
     b = json.loads(r.stdout.splitlines()[0])
     assert "error" in b and b["n_gpus"] == 2 and b["value"] is None
+
+
+@pytest.mark.timeout(300)
+def test_plain_bench_invocation_starts_eight_ranks():
+    """The driver's N = 8 command form (`python bench.py --gpus 8`), rehearsed on the CPU: eight ranks meet over gloo, rank 0's
+    ONE line reaches stdout.  (RCCL with 8 ranks is the driver's run on an 8-GPU node: rccl.h:220.)"""
+    import json
+    r = _plain_bench(["--gpus", "8", "--steps", "3", "--backend", "gloo", "--dry-run-ranks"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 8 and len(set(b["pids"])) == 8
+
+
+@pytest.mark.timeout(300)
+def test_failed_job_leaves_one_json_error_line():
+    """A rank that dies before rank 0 printed its line: the parent exits non-zero AND leaves one parseable line with the exit
+    code and the end of the ranks' output (the driver's record of a failed N = 8 run then carries a diagnosis)."""
+    import json
+    r = _plain_bench(["--gpus", "2", "--backend", "gloo", "--dry-run-ranks", "--hang-rank", "1", "--hang-at-step", "0"])
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["rc"] == r.returncode and b["value"] is None
+    assert any("injected failure of rank 1" in x for x in b["rank_errors"]) and 0 < len(b["stderr_tail"]) <= 2048
+    assert '"rank": 1' in r.stderr                      # the rank's own one-line record came first
+
+
+def test_world8_split_plans_stay_within_the_memory_budget():
+    """BASELINE configs[3] (512 streams on 8 GPUs): the five stream splits bench.py times at N = 8 (emspec.shard.trial_splits),
+    the chunking of every rank and the root's gather buffers (expanded and packed form) - every rank's device memory stays
+    under 48 GB (of the MI355X's 288 GB), the splits cover all 512 streams, the root never has fewer streams than chunks.
+    The trials' wall clock is bounded separately at run time: --trial-budget-s (60 s) + the 2-step warm-up."""
+    import emspec
+    from emspec import shard
+    world, S, L, n, hop, R, nbuf, nch = 8, 64, 1 << 22, 4096, 256, 1024, 2, 2
+    C = (L - n) // hop + 1
+    wire_bound = emspec.wire_bound          # (a host function of the library: no device needed)
+    plans = shard.trial_splits(world, world * S, nch)
+    assert [p[0] for p in plans] == [64, 50, 36, 22, 8] and len(plans) <= 5
+    for counts in plans:
+        assert sum(counts) == world * S and len(counts) == world and counts[0] >= nch
+        assert max(counts[1:]) - min(counts[1:]) <= 1
+        firsts = shard.first_streams(counts)
+        assert firsts[0] == 0 and all(firsts[r + 1] == firsts[r] + counts[r] for r in range(world - 1))
+        for packed in (True, False):
+            worst = max(shard.job_device_bytes(counts, r, L, C, R, nbuf, nch, packed, wire_bound) for r in range(world))
+            assert worst < 48e9, (counts, packed, worst)
+    # the modelled default when no trial fits the budget is one of the planned splits
+    assert shard.root_light_counts(world, world * S, 0, max(nch, world * S - (world - 1) * (S + S // 8))) == plans[-1]
