@@ -655,7 +655,7 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
         HIPCHK(e, launch_exact_tile_scatter(sk.rec_q, sk.rec_key, n, pd, m, e->d_lut, sc, C, db ? db + s0 * col_cells : nullptr,
                                             rgba ? rgba + 4 * s0 * col_cells : nullptr,
                                             index ? index + s0 * col_cells : nullptr, st, low_need ? ebin_host : nullptr,
-                                            low_need ? e->d_xlow : nullptr, low_need ? e->xlow_bytes : 0));
+                                            low_need ? e->d_xlow : nullptr, low_need));   // (only what was cleared above: the buffer may be larger)
     }
     if (low_need) HIPCHK(e, hipEventRecord(e->xlow_event, st));
     return EMSPEC_OK;
@@ -791,6 +791,7 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
         if (xrl >= 0) {   // the stamped build of exact_fused4096_lr_kernel (slots: exact_fused_lr.hip.inc)
             if ((rc = exact_lr_prepare(e, xpd, xrl, S, Cx, e->stream))) return rc;
             HIPCHK(e, launch_exact_fused_lr(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, xrl, e->d_xlow, e->xlow_bytes, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
+            if (xrl > 0) HIPCHK(e, hipEventRecord(e->xlow_event, e->stream));   // (every launch on the scratch: later ones on other streams wait for it)
             if (waves) *waves = 16;
             if (!cycles) return EMSPEC_OK;
             unsigned long long* dl = nullptr;
@@ -937,7 +938,10 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
                     break;
                 }
                 herr = hipMemcpyAsync(pk->wire + at, q.wire + (size_t)i * al(wire_s), (size_t)bytes, hipMemcpyDeviceToHost, e->stream_out);
-                pk->offsets[s0 + i + 1] = at + bytes;
+                // every image STARTS on a 16-byte boundary: the fixed part (32 + 4 C (1 + R/32) bytes) is a multiple of 4 only, so
+                // up to 12 bytes of slack follow an image (stream s occupies [offsets[s], offsets[s+1]), slack included; the
+                // unpackers take the image's real size from its header)
+                pk->offsets[s0 + i + 1] = (at + bytes + 15) & ~(int64_t)15;
             }
         }
         if (herr == hipSuccess && rc == EMSPEC_OK) herr = hipEventRecord(ev_out[b], e->stream_out);

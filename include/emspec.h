@@ -430,7 +430,9 @@ int emspec_wire_unpack(emspec_engine* e, const uint8_t* wire_dev, int64_t wire_b
  * Host-buffer batch whose palette-index columns leave the device PACKED: the same columns as emspec_batch(out->index), but
  * what crosses PCIe is the lossless wire image above (~186 B instead of 1,024 B per column on typical audio), ONE IMAGE
  * PER STREAM, tightly packed into `wire` (host memory, pinned for full speed) in stream order: stream s occupies
- * wire[offsets[s] .. offsets[s+1]) (offsets: streams + 1 entries, offsets[0] = 0, every image 16-byte aligned).
+ * wire[offsets[s] .. offsets[s+1]) (offsets: streams + 1 entries, offsets[0] = 0; every image STARTS on a 16-byte boundary,
+ * so up to 12 bytes of unspecified slack may follow an image inside its slot - an image's own size is in its header, and
+ * emspec_wire_unpack_host / emspec_wire_unpack accept the slot as it is).
  * wire_capacity = streams x emspec_wire_bound(columns, rows) always suffices; EMSPEC_ERR_INVALID_ARG when the images do not
  * fit.  Runs the three-stage pipeline of emspec_batch (H2D | kernels + pack | D2H on three HIP streams); rows % 4 == 0.
  * Serves: the renderer-side batched computeColumns when the host keeps or forwards the columns compressed

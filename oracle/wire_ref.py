@@ -21,7 +21,7 @@ def fixed_bytes(columns, rows):
 
 
 def bound(columns, rows):
-    return fixed_bytes(columns, rows) + columns * rows + 16
+    return fixed_bytes(columns, rows) + columns * rows + 32
 
 
 def pack(index):

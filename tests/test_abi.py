@@ -157,6 +157,19 @@ def test_flagship_kernels_do_not_spill():
         assert int(meta["vgpr_count"]) <= 128, (name, meta)
         seen += 1
     assert seen >= 14, seen
+    # the EXACT mode's flagships: the one-kernel N = 4096 path in its branch-free form, and the N = 16384 frames
+    # kernel of the records path - 1024-thread workgroups, so 128 VGPRs is the ceiling and a spill is paid by sixteen lock-step waves
+    xseen = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n", text):
+        name = m.group(1)
+        if not any(k in name for k in ("exact_fused4096_lr_kernelILb0ELb1", "exact_frames16384_kernelILb1ELb0", "exact_frames16384_kernelILb0ELb0")):
+            continue
+        blk = text[m.start() - 400:m.start() + 1600]
+        meta = dict(re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk))
+        assert int(meta["vgpr_spill_count"]) == 0 and int(meta["private_segment_fixed_size"]) == 0, (name, meta)
+        assert int(meta["vgpr_count"]) <= 128, (name, meta)
+        xseen += 1
+    assert xseen >= 3, xseen
 
 
 def test_display_laws_are_shared_by_every_binding():

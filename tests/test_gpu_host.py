@@ -155,3 +155,34 @@ def test_packed_batch_other_row_counts_and_sizes(rows, n, hop):
         wire, offs = e.batch_packed(pcm, n, hop, True)
         for s in range(S):
             assert np.array_equal(emspec.wire_unpack_host(wire[offs[s]:offs[s + 1]], frames, rows), ref[s]), (rows, s)
+
+
+@pytest.mark.parametrize("columns", [401, 1021, 7])
+def test_packed_batch_images_start_on_16_byte_boundaries_for_any_column_count(columns):
+    """an image is 32 + 4 C (1 + R/32) + pad16(payload) bytes - a multiple of 4 only - so with C = 401 or 1021 (rows
+    1024) the images used to start 4 mod 16.  Every image now STARTS on a 16-byte boundary (the header's promise); the <= 12
+    bytes of slack inside a slot are not part of the image, and both unpackers take the slot as it is."""
+    n, hop, S = 1024, 256, 5
+    L = n + hop * (columns - 1)
+    pcm = synth.streams(S, L)
+    with emspec.Engine(mode=emspec.MODE_EXACT) as e:
+        assert emspec.num_columns(L, n, hop) == columns
+        ref = e.batch(pcm, n, hop, True, want=("index",))["index"]
+        for pinned in (True, False):
+            pin = _pinned(pcm) if pinned else None
+            pw = emspec.PinnedArray((S * emspec.wire_bound(columns, e.rows),), np.uint8) if pinned else None
+            try:
+                if pinned:
+                    pw.array[...] = 0xEE
+                wire, offs = e.batch_packed(pin.array if pinned else pcm, n, hop, True, wire=pw.array if pinned else None)
+                assert offs[0] == 0 and np.all(offs % 16 == 0) and np.all(np.diff(offs) > 0)
+                assert offs[-1] <= S * emspec.wire_bound(columns, e.rows)
+                for s in range(S):
+                    image = W.pack(ref[s])
+                    slot = wire[offs[s]:offs[s + 1]]
+                    assert 0 <= slot.size - image.size <= 12
+                    assert np.array_equal(slot[:image.size], image), s
+                    assert np.array_equal(emspec.wire_unpack_host(slot, columns, e.rows), ref[s])
+            finally:
+                if pinned:
+                    pin.close(); pw.close()
