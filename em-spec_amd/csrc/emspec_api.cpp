@@ -403,7 +403,7 @@ int emspec_device_status(emspec_engine* e) {
 }
 const char* emspec_device_arch(const emspec_engine* e) { return e ? e->arch.c_str() : ""; }
 }  // extern "C"
-// EXACT mode, N = 4096: rows of the ring that the no-parking kernel (exact_fused_lr.hip.inc) keeps in global memory, or -1
+// EXACT mode, N = 4096 / 2048 / 1024: rows of the ring that the no-parking kernel (exact_fused_lr.hip.inc) keeps in global memory, or -1
 // when it does not serve this engine's shape or axis.  The axis is served when at most 6 % of a frame's bins lie below row
 // rl (on the default log axis at hop 256: rl = 448 of 1024 rows, 38 of 2,049 bins); each of those costs a device-scope
 // atomic, so a linear axis (44 % of the bins there) stays on round 4's kernel, which parks instead.
@@ -591,10 +591,10 @@ static int run_columns(emspec_engine* e, const PlanDev& pd, const DbMap& m, cons
 
 // The low-row scratch of the no-parking EXACT kernel: grown on demand; a launch on another HIP stream than the previous one
 // waits for it (one scratch per engine: two launches must not run side by side on it)
-static int exact_lr_prepare(emspec_engine* e, const ExactPlanDev& pd, int rl, int S, int64_t C, hipStream_t st) {
+static int exact_lr_prepare(emspec_engine* e, int n, const ExactPlanDev& pd, int rl, int S, int64_t C, hipStream_t st) {
     if (rl <= 0) return EMSPEC_OK;
     int rc;
-    const size_t need = exact_fused_lr_scratch_bytes(pd, rl, S, C);
+    const size_t need = exact_fused_lr_scratch_bytes(n, pd, rl, S, C);
     if (need > e->xlow_bytes) {
         if (e->xlow_used) HIPCHK(e, hipEventSynchronize(e->xlow_event));      // the old buffer may still be in use
         if ((rc = grow(e, (void**)&e->d_xlow, &e->xlow_bytes, need))) return rc;
@@ -614,7 +614,7 @@ static int run_columns_exact(emspec_engine* e, const Plan& p, const float* pcm, 
     const ExactDbMap m = exact_db_map(e, n, pd);
     const int rl = exact_lr_rows(e, n, pd);
     if (rl >= 0) {   // one kernel, no records, no parking (exact_fused_lr.hip.inc)
-        if ((rc = exact_lr_prepare(e, pd, rl, S, C, st))) return rc;
+        if ((rc = exact_lr_prepare(e, n, pd, rl, S, C, st))) return rc;
         HIPCHK(e, launch_exact_fused_lr(n, pd, m, e->d_lut, pcm, L, S, C, rl, e->d_xlow, e->xlow_bytes, db, rgba, index, st));
         if (rl > 0) HIPCHK(e, hipEventRecord(e->xlow_event, st));
         return EMSPEC_OK;
@@ -789,7 +789,7 @@ int emspec_debug_phase_cycles(emspec_engine* e, const float* pcm_dev, int32_t S,
         const int64_t Cx = emspec_num_columns(L, n, hop);
         const int xrl = exact_lr_rows(e, n, xpd);
         if (xrl >= 0) {   // the stamped build of exact_fused4096_lr_kernel (slots: exact_fused_lr.hip.inc)
-            if ((rc = exact_lr_prepare(e, xpd, xrl, S, Cx, e->stream))) return rc;
+            if ((rc = exact_lr_prepare(e, n, xpd, xrl, S, Cx, e->stream))) return rc;
             HIPCHK(e, launch_exact_fused_lr(n, xpd, xm, e->d_lut, pcm_dev, L, S, Cx, xrl, e->d_xlow, e->xlow_bytes, db_dev, nullptr, index_dev, e->stream, nullptr, groups));
             if (xrl > 0) HIPCHK(e, hipEventRecord(e->xlow_event, e->stream));   // (every launch on the scratch: later ones on other streams wait for it)
             if (waves) *waves = 16;

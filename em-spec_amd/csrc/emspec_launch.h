@@ -105,7 +105,7 @@ hipError_t launch_exact_fused(int n, const ExactPlanDev& pl, const ExactDbMap& m
 // in a per-workgroup scratch in global memory (device-scope atomics only).  exact_fused_lr_low_rows: rl for the shape
 // (rows, D), or -1 when the shape is not served; whether the AXIS is (few bins below row rl) is the caller's decision.
 int exact_fused_lr_low_rows(int n, const ExactPlanDev& pl);
-size_t exact_fused_lr_scratch_bytes(const ExactPlanDev& pl, int rl, int S, int64_t C);
+size_t exact_fused_lr_scratch_bytes(int n, const ExactPlanDev& pl, int rl, int S, int64_t C);
 hipError_t launch_exact_fused_lr(int n, const ExactPlanDev& pl, const ExactDbMap& m, const uint8_t* lut, const float* pcm,
                                  int64_t L, int S, int64_t C, int rl, unsigned long long* low, size_t low_bytes, float* db,
                                  uint8_t* rgba, uint8_t* index, hipStream_t st, unsigned long long* stamps = nullptr,

@@ -276,9 +276,12 @@ def test_exact_mode_guards(xengine, engine):
     with pytest.raises(emspec.EmspecError) as ei:
         engine.parity_dump_exact(pcm, 1024, 256, True, 0, 4)
     assert ei.value.code == emspec.ERR_STATE
-    # emspec_uses_fused answers for EXACT engines since ABI 2: one kernel at N = 4096 when the u64 ring fits, records otherwise
+    # emspec_uses_fused answers for EXACT engines since ABI 2: one kernel at N = 4096 / 2048 / 1024 (round 6) when the u64 ring fits
+    # LDS beside the planes - whole, or with its sparse low rows in the L2 scratch - records otherwise
     assert xengine.fused(4096, 256, True) and xengine.fused(4096, 1024, False) and not xengine.fused(4096, 128, True)
-    assert not xengine.fused(16384, 512, True) and not xengine.fused(1024, 256, True)
+    assert not xengine.fused(16384, 512, True) and not xengine.fused(8192, 512, True)
+    assert xengine.fused(1024, 256, True) and xengine.fused(2048, 256, True) and xengine.fused(2048, 128, True)
+    assert not xengine.fused(1024, 64, True)
     assert xengine.mode == emspec.MODE_EXACT and engine.mode == emspec.MODE_FAST
     with pytest.raises(emspec.EmspecError):
         emspec.Engine(mode=7)
@@ -373,6 +376,49 @@ def test_exact_fused_kernel_shapes(hop, frames, S, reassign, rows, seglen, kw, m
     pcm = _pcm(n, hop, frames, S=S, extra=5)
     with emspec.Engine(mode=emspec.MODE_EXACT, diag=True, rows=rows, **kw) as e:
         out = e.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
+    odb, orgba, oidx, _ = O.batch_exact(O.make_cfg(n, hop, reassign, rows=rows, **kw), pcm)
+    assert out["db"].shape == odb.shape == (S, frames, rows)
+    assert np.array_equal(out["index"], oidx), f"{np.sum(out['index'] != oidx)} palette indices differ"
+    assert np.array_equal(out["db"].view(np.uint32), odb.view(np.uint32)), \
+        f"{np.sum(out['db'].view(np.uint32) != odb.view(np.uint32))} dB cells differ"
+    assert np.array_equal(out["rgba"], orgba)
+
+
+SMALL_FUSED_CASES = [  # n, hop, frames, S, reassign, rows, seglen, engine settings
+    (1024, 256, 300, 2, True, 1024, 64, {}),      # D = 2, four frames per team and half-iteration: 12 ring slots, low rows in the L2 scratch
+    (1024, 256, 131, 1, True, 1024, 33, {}),      # odd segment length, blocks that straddle the segment's end
+    (1024, 256, 3, 2, True, 1024, 0, {}),         # fewer frames than one block
+    (1024, 256, 1, 1, True, 1024, 0, {}),
+    (1024, 128, 200, 2, True, 1024, 0, {}),       # D = 4
+    (1024, 64, 150, 1, True, 1024, 0, {}),        # D = 8: 24 slots, 604 low rows - more low quads than the team has threads: records path
+    (1024, 96, 150, 1, True, 1024, 0, {}),        # D = 6: 20 slots, 520 low rows: records path too
+    (1024, 100, 90, 1, True, 1024, 0, {}),        # a hop that is no power of two
+    (1024, 256, 120, 2, False, 1024, 48, {}),     # reassignment off: D = 0, the branchy per-bin core
+    (1024, 256, 90, 2, True, 512, 0, {}),         # the whole ring in LDS (no low rows)
+    (1024, 256, 90, 1, True, 64, 0, {}),
+    (1024, 256, 90, 2, True, 1024, 0, {"power_floor": 0.0}),
+    (2048, 256, 300, 2, True, 1024, 64, {}),      # D = 4, two frames per team and half-iteration
+    (2048, 128, 140, 1, True, 1024, 37, {}),      # D = 8: 20 slots
+    (2048, 512, 5, 2, True, 1024, 0, {}),
+    (2048, 300, 80, 1, True, 1024, 0, {}),
+    (2048, 256, 100, 2, False, 1024, 0, {}),
+    (2048, 256, 90, 1, True, 256, 0, {"gain": 3.5, "db_range": 58.0, "gate_db": -65.0}),
+]
+
+
+@pytest.mark.parametrize("n,hop,frames,S,reassign,rows,seglen,kw", SMALL_FUSED_CASES)
+def test_exact_fused_small_sizes(n, hop, frames, S, reassign, rows, seglen, kw, monkeypatch):
+    """The one-kernel EXACT path at N = 1024 and 2048 (round 6: exact_fused4096_lr_kernel<.., S>, the 4096-point carrier network with
+    its first S stages skipped = 2 / 4 frames per team and half-iteration): the engine reports a fused kernel for the shape, and
+    the bytes equal the binary64 bit model (dB bits, palette index, RGBA) - and the records path's (EMSPEC_EXACT_RECORDS=1)."""
+    if seglen:
+        monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
+    pcm = _pcm(n, hop, frames, S=S, extra=5)
+    with emspec.Engine(mode=emspec.MODE_EXACT, diag=True, rows=rows, **kw) as e:
+        # (N = 1024 at hop < 128: more than 512 low rows - more low quads per block than the team has threads - records path)
+        assert e.fused(n, hop, reassign) == (n == 2048 or hop >= 128)
+        out = e.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
+        e.device_status()
     odb, orgba, oidx, _ = O.batch_exact(O.make_cfg(n, hop, reassign, rows=rows, **kw), pcm)
     assert out["db"].shape == odb.shape == (S, frames, rows)
     assert np.array_equal(out["index"], oidx), f"{np.sum(out['index'] != oidx)} palette indices differ"
