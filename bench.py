@@ -993,8 +993,12 @@ def main():
             xeng = emspec.Engine(device=dev_index, mode=emspec.MODE_EXACT)
             xname = "EXACT mode, configs[2]: 64 streams, FFT 4096, hop 256, reassignment ON"
             x4name = "EXACT mode, configs[4]: 64 streams, FFT 16384, hop 512, reassignment ON"
+            x1name = "EXACT mode, 64 streams, FFT 1024, hop 256, reassignment ON"
+            x2name = "EXACT mode, 64 streams, FFT 2048, hop 256, reassignment ON"
             for name, Sx, nx, hx, reps in ((xname, 64, 4096, 256, 3),
-                                           (x4name, 64, 16384, 512, 2)):
+                                           (x4name, 64, 16384, 512, 2),
+                                           (x1name, 64, 1024, 256, 5),      # one kernel since round 6 (four frames per team and half-iteration)
+                                           (x2name, 64, 2048, 256, 5)):
                 Cx = emspec.num_columns(L, nx, hx)
                 px = pcm[:Sx].contiguous()
                 dbx = db.view(-1)[:Sx * Cx * R].view(Sx, Cx, R)
@@ -1011,6 +1015,10 @@ def main():
                 cfgs[x4name]["roofline"]["traffic"] = px4.get("hbm_bytes_per_launch") if fx4 else None
                 cfgs[x4name]["roofline"]["traffic_source"] = f"{px4['file']}{'' if fx4 else ' (STALE: kernels changed since, withheld)'}"
                 cfgs[x4name]["kernel_split"] = px4.get("kernel_split") if fx4 else None
+            px1, fx1 = profile_for("exact_n1024", lib_sha)
+            if px1:
+                cfgs[x1name]["roofline"]["traffic"] = px1.get("hbm_bytes_per_launch") if fx1 else None
+                cfgs[x1name]["roofline"]["traffic_source"] = f"{px1['file']}{'' if fx1 else ' (STALE: kernels changed since, withheld)'}"
             xeng.device_status()      # a protocol error of the fused kernels' bounded waits would surface here
             xeng.close()
             if not args.no_cpu_baseline:

@@ -455,8 +455,12 @@ int emspec_get_tables(emspec_engine* e, int32_t n, float* edges_bins, float* twi
  * hop 512 or 1024; n = 16384 at any hop whose ring has at most 33 slots of 1024
  * rows, e.g. hop 512; at most 1024 rows), 0 if the generic two-kernel path
  * (per-bin records + LDS tile / walking-ring scatter).  EXACT-mode engines:
- * 1 for n = 4096 at any hop whose u64 column ring fits in LDS beside the tables
- * (hop >= 228 at 1024 rows: exact_fused.hip.inc), else 0.  Same results either way. */
+ * 1 for n = 4096, 2048 and 1024 when the u64 column ring (2 D + 2 * 4096 / n slots) fits in LDS
+ * beside the 64 KB of binary64 planes - whole, or with its low rows in a per-workgroup scratch in
+ * global memory when at most 6 % of a frame's bins fall there (exact_fused_lr.hip.inc; on the default
+ * log axis e.g. n = 4096 / hop 256, n = 2048 / hop 128 or 256, n = 1024 / hop 128 or 256; other
+ * axes at n = 4096 run exact_fused.hip.inc's kernel, which parks the ring under the planes) - else 0:
+ * n = 8192 and 16384 run the two-kernel records path.  Same results either way. */
 int emspec_uses_fused(const emspec_engine* e, int32_t n, int32_t hop, int32_t reassign);
 
 /* Name of the device the engine runs on, e.g. "gfx950". */
