@@ -46,3 +46,11 @@ def test_fuzz_slice_exact_mode():
     three-window method (0 mismatches expected: asserted from the tool's summary line)."""
     out = _run("fuzz_exact.py", 150, 507, {"EMSPEC_FUZZ_DIAG": "1"})
     assert "vs the independent float64 method: 0 mismatches" in out, out[-1500:]
+
+
+@pytest.mark.timeout(900)
+def test_fuzz_slice_live_multi_stream():
+    """60 random live sessions (round 6: emspec_columns / emspec_push_samples_multi / flush / reset_stream; either mode, any
+    size, 1..8 streams, sub-hop and over-long blocks, page-locked or pageable buffers, one stream restarted mid-session) against
+    the oracle's batch columns: EXACT bytes, float32 within 8.7e-4 dB."""
+    _run("fuzz_live.py", 60, 508)

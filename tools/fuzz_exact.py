@@ -24,7 +24,7 @@ for ci in range(cases):
     S = int(rng.integers(1, 4))
     D = -(-n // (2 * hop)) if reassign else 0
     frames = int(rng.integers(1, (40 if D <= 64 else 12) + 1))
-    if n == 4096 and rng.integers(0, 2):          # the fused exact kernel (round 4): longer walks, several segments (short forced segments below)
+    if n in (1024, 2048, 4096) and rng.integers(0, 2):   # the one-kernel exact path (N = 4096: round 4; 2048 / 1024: round 6): longer walks, several segments (short forced segments below)
         frames = int(rng.integers(1, 260))
     if n * frames * S > 4e6:
         frames = max(1, int(4e6 / (n * S)))
@@ -41,7 +41,7 @@ for ci in range(cases):
     elif kind == 3:
         pcm = (pcm * 0).astype(np.float32) if rng.integers(0, 2) else np.sign(pcm).astype(np.float32) * np.float32(0.7)
     desc = f"case {ci}: n={n} hop={hop} rows={rows} re={reassign} S={S} frames={frames} L={L} kind={kind} {kw}"
-    if n == 4096 and rng.integers(0, 2):
+    if n in (1024, 2048, 4096) and rng.integers(0, 2):
         os.environ["EMSPEC_SEGLEN"] = str(int(rng.integers(2, 140)))     # honoured by libemspec_diag.so only (EMSPEC_FUZZ_DIAG=1)
     else:
         os.environ.pop("EMSPEC_SEGLEN", None)
