@@ -347,7 +347,7 @@ int emspec_create(const emspec_config* cfg, emspec_engine** out) {
         // ONE engine - H2D and D2H then take turns (measured: index out 3.4e7 instead of 4.4e7 columns/s)
         if (hipStreamCreateWithFlags(&e->stream_in, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&e->stream_out, hipStreamNonBlocking) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "hipStreamCreate failed"); break; }
-        if (hipMalloc(&e->d_lut, 1024) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_OUT_OF_MEMORY, "hipMalloc(lut) failed"); break; }
+        if (hipMalloc(&e->d_lut, 1024 + 64) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_OUT_OF_MEMORY, "hipMalloc(lut) failed"); break; }
         uint8_t lut[1024];
         default_lut(lut);
         if (hipMemcpy(e->d_lut, lut, 1024, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(nullptr, EMSPEC_ERR_HIP, "lut upload failed"); break; }
@@ -368,13 +368,8 @@ void emspec_destroy(emspec_engine* e) {
     drop_plans(e);
     (void)hipFree(e->d_xlow);
     if (e->xlow_event) (void)hipEventDestroy(e->xlow_event);
-    (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage); (void)hipFree(e->d_ring);
-    (void)hipFree(e->d_frame); (void)hipFree(e->d_coldb); (void)hipFree(e->d_colrgba);
-    (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak); (void)hipFree(e->d_pstate);
-    (void)hipFree(e->d_sbuf[0]); (void)hipFree(e->d_sbuf[1]); (void)hipFree(e->d_pushdb); (void)hipFree(e->d_pushrgba);
-    if (e->h_frame) (void)hipHostFree(e->h_frame);
-    if (e->h_coldb) (void)hipHostFree(e->h_coldb);
-    if (e->h_colrgba) (void)hipHostFree(e->h_colrgba);
+    (void)hipFree(e->d_lut); (void)hipFree(e->d_hist); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_raw); (void)hipFree(e->d_post); (void)hipFree(e->d_peak);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->stream_in) (void)hipStreamDestroy(e->stream_in);
     if (e->stream_out) (void)hipStreamDestroy(e->stream_out);
@@ -441,9 +436,7 @@ static void drop_plans(emspec_engine* e) {
 
 int emspec_set_row_edges_hz(emspec_engine* e, const float* edges_hz, int32_t count) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
-    if (e->st_reassign >= 0 && e->st_fed > e->st_emitted) return fail(e, EMSPEC_ERR_STATE, "columns are pending; flush or reset before changing the row edges");
-    for (int s = 0; s < e->live.S; ++s)
-        if (e->live.fed[s] > e->live.emitted[s]) return fail(e, EMSPEC_ERR_STATE, "columns of the live session are pending; flush or reset before changing the row edges");
+    if (live_pending(e)) return fail(e, EMSPEC_ERR_STATE, "columns are pending; flush or reset before changing the row edges");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (!edges_hz) {   // back to the configured log axis
@@ -708,8 +701,7 @@ int emspec_debug_fused_error(emspec_engine* e) {
 int emspec_debug_occupy(emspec_engine* e, int32_t groups, int32_t usec, void* hip_stream) {
     if (!e || groups < 1 || groups > 4096 || usec < 1 || usec > 2000000) return fail(e, EMSPEC_ERR_INVALID_ARG, "bad argument");
     HIPCHK(e, hipSetDevice(e->device));
-    if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
-    HIPCHK(e, launch_occupy(groups, usec, reinterpret_cast<unsigned*>(e->d_coldb), (hipStream_t)hip_stream));
+    HIPCHK(e, launch_occupy(groups, usec, reinterpret_cast<unsigned*>(e->d_lut) + 256, (hipStream_t)hip_stream));   // (a spare word behind the palette)
     return EMSPEC_OK;
 }
 
@@ -1184,295 +1176,11 @@ int emspec_set_display(emspec_engine* e, float smoothing, float agc_strength) {
 
 int emspec_reset(emspec_engine* e) {
     if (!e) return EMSPEC_ERR_INVALID_ARG;
-    if (e->d_pstate) { (void)hipSetDevice(e->device); (void)hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream); }
-    e->st_n = 0; e->st_hop = 0; e->st_reassign = -1; e->st_D = 0; e->st_W = 0; e->st_mode = 0;
-    e->st_fed = 0; e->st_emitted = 0; e->st_have = 0;
-    e->st_pending.clear();
-    live_reset(e);
+    live_reset(e);   // both streaming sessions: the single-stream calls' and the live multi-stream one (buffers are kept)
     return EMSPEC_OK;
 }
 
-// finalize ring slot of absolute column c (or the empty slot when c < 0), copy out, clear the slot
-static int emit_column(emspec_engine* e, int64_t c, float* out_db, uint8_t* out_rgba) {
-    const int R = e->cfg.rows;
-    const int W = e->st_W;
-    const int64_t slot = c < 0 ? W : c % W;
-    const DbMap m = db_map(e, e->st_n);
-    const size_t cellb = e->exact() ? 8 : 4;   // EXACT mode: the ring holds u64 fixed-point cells
-    float* cells = reinterpret_cast<float*>(reinterpret_cast<char*>(e->d_ring) + (size_t)slot * R * cellb);
-    const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
-    if (e->exact()) {
-        Plan* p;
-        int rc;
-        if ((rc = get_plan(e, e->st_n, &p))) return rc;
-        const ExactPlanDev xpd = exact_plan_dev(e, *p, e->st_hop, e->st_reassign);
-        HIPCHK(e, launch_exact_finalize(reinterpret_cast<const unsigned long long*>(cells), R, exact_db_map(e, e->st_n, xpd),
-                                        e->d_lut, (out_db || post) ? e->d_coldb : nullptr,
-                                        (out_rgba && !post) ? e->d_colrgba : nullptr, nullptr, e->stream));
-    } else
-    HIPCHK(e, launch_finalize(cells, R, m, e->d_lut, (out_db || post) ? e->d_coldb : nullptr,
-                              (out_rgba && !post) ? e->d_colrgba : nullptr, nullptr, e->stream));
-    if (post) {
-        if (!e->d_pstate) {
-            HIPCHK(e, hipMalloc(&e->d_pstate, (size_t)(4096 + 4) * 4));
-            HIPCHK(e, hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream));
-        }
-        HIPCHK(e, launch_post_column(e->d_coldb, R, e->smoothing, e->agc, e->cfg.db_top, m, e->d_lut,
-                                     out_rgba ? e->d_colrgba : nullptr, e->d_pstate, e->d_pstate + 4, e->stream));
-    }
-    if (out_db) HIPCHK(e, hipMemcpyAsync(out_db, e->d_coldb, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
-    if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba, e->d_colrgba, (size_t)R * 4, hipMemcpyDeviceToHost, e->stream));
-    if (c >= 0) HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)R * cellb, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    return EMSPEC_OK;
-}
-
-int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop, int32_t reassign, float* out_db,
-                  uint8_t* out_rgba, int32_t rows, int64_t* out_column) {
-    if (!e || !frame) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
-    int rc = check_shape(e, n, hop);
-    if (rc) return rc;
-    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
-    reassign = reassign ? 1 : 0;
-    HIPCHK(e, hipSetDevice(e->device));
-    const int R = e->cfg.rows;
-    if (e->st_reassign < 0) {
-        // first frame of a stream: set up the ring; the stream state is committed only after every allocation succeeded
-        const int D = latency(n, hop, reassign), W = 2 * D + 1;
-        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 8))) return rc;   // 8: room for EXACT mode's u64 cells
-        if ((rc = grow(e, (void**)&e->d_frame, &e->frame_bytes, (size_t)n * 4))) return rc;
-        if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
-        if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
-        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 8, e->stream));
-        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W;
-        e->st_mode = 1;
-    } else if (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 1) {
-        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
-    }
-    Plan* p;
-    if ((rc = get_plan(e, n, &p))) return rc;
-    const PlanDev pd = plan_dev(e, *p, hop, reassign);
-    const int64_t j = e->st_fed;
-    FrameSinks sk;
-    sk.hist = e->d_ring;
-    sk.hist_slots = e->st_W;
-    sk.total_cols = INT64_MAX;
-    sk.ring = 1;
-    sk.col_offset = j;   // the staged frame sits at offset 0 but is absolute frame j
-    const int64_t c = j - e->st_D;   // column completed by this frame
-    const bool post = (e->smoothing > 0.0f || e->agc > 0.0f) && c >= 0;
-    if (out_column) *out_column = c >= 0 ? c : -1;
-    if (e->exact()) {
-        // EXACT mode: u64 ring in HBM (global integer atomics), then the binary64 finalize of the finished column
-        ExactSinks xs;
-        xs.hist = reinterpret_cast<unsigned long long*>(e->d_ring);
-        xs.hist_slots = e->st_W;
-        xs.total_cols = INT64_MAX;
-        xs.ring = 1;
-        xs.col_offset = j;
-        HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, launch_exact_frames(n, exact_plan_dev(e, *p, hop, reassign), e->d_frame, n, 1, 0, 1, xs, e->stream));
-        e->st_fed = j + 1;
-        if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
-    } else if (!post && (out_db || out_rgba)) {
-        // One launch, no DMA: the frame's workgroup reads the samples from page-locked host memory, scatters,
-        // and emits the finished column straight into page-locked host memory (FrameSinks::fin_*).
-        if (e->h_frame_bytes < (size_t)n * 4) {
-            if (e->h_frame) { HIPCHK(e, hipHostFree(e->h_frame)); e->h_frame = nullptr; e->h_frame_bytes = 0; }
-            HIPCHK(e, hipHostMalloc((void**)&e->h_frame, (size_t)n * 4, hipHostMallocDefault));
-            e->h_frame_bytes = (size_t)n * 4;
-        }
-        if (!e->h_coldb) HIPCHK(e, hipHostMalloc((void**)&e->h_coldb, (size_t)4096 * 4, hipHostMallocDefault));
-        if (!e->h_colrgba) HIPCHK(e, hipHostMalloc((void**)&e->h_colrgba, (size_t)4096 * 4, hipHostMallocDefault));
-        std::memcpy(e->h_frame, frame, (size_t)n * 4);
-        sk.fin_db = out_db ? e->h_coldb : nullptr;
-        sk.fin_rgba = out_rgba ? reinterpret_cast<uint32_t*>(e->h_colrgba) : nullptr;
-        sk.fin_lut = reinterpret_cast<const uint32_t*>(e->d_lut);
-        sk.fin_col = c;
-        sk.fin_map = db_map(e, n);
-        HIPCHK(e, launch_frames(n, pd, e->h_frame, n, 1, 0, 1, sk, e->stream));
-        e->st_fed = j + 1;
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (out_db) std::memcpy(out_db, e->h_coldb, (size_t)R * 4);
-        if (out_rgba) std::memcpy(out_rgba, e->h_colrgba, (size_t)R * 4);
-    } else {
-        HIPCHK(e, hipMemcpyAsync(e->d_frame, frame, (size_t)n * 4, hipMemcpyHostToDevice, e->stream));
-        HIPCHK(e, launch_frames(n, pd, e->d_frame, n, 1, 0, 1, sk, e->stream));
-        e->st_fed = j + 1;
-        if ((rc = emit_column(e, c, out_db, out_rgba))) return rc;
-    }
-    if (c >= 0) e->st_emitted = c + 1;
-    return EMSPEC_OK;
-}
-
-
-// ---- streaming by sample blocks (per-stream sample ring + pending-column ring) ----
-namespace {
-constexpr int kPushFrames = 64;   // frames per launch in sample mode; the ring holds 2D + kPushFrames columns
-
-// frames completed once `total` samples of the stream have been seen
-int64_t frames_after(int64_t total, int n, int hop) { return total >= n ? (total - n) / hop + 1 : 0; }
-}  // namespace
-
-int64_t emspec_push_columns(const emspec_engine* e, int64_t count, int32_t n, int32_t hop, int32_t reassign) {
-    if (!e || count < 0 || !supported_fft(n) || hop < 1 || hop > n) return -1;
-    const int D = latency(n, hop, reassign ? 1 : 0);
-    const bool live = e->st_mode == 2;
-    const int64_t fed = live ? e->st_fed : 0;
-    const int64_t seen = live ? e->st_fed * (int64_t)hop + e->st_have + (int64_t)e->st_pending.size() : 0;
-    const int64_t after = frames_after(seen + count, n, hop);
-    const int64_t before_cols = fed > D ? fed - D : 0, after_cols = after > D ? after - D : 0;
-    return after_cols - before_cols;
-}
-
-int emspec_push_samples(emspec_engine* e, const float* samples, int64_t count, int32_t n, int32_t hop, int32_t reassign,
-                        float* out_db, uint8_t* out_rgba, int32_t rows, int64_t max_columns, int64_t* out_count,
-                        int64_t* out_first_column) {
-    if (!e || (!samples && count > 0) || count < 0) return fail(e, EMSPEC_ERR_INVALID_ARG, "null argument");
-    int rc = check_shape(e, n, hop);
-    if (rc) return rc;
-    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
-    reassign = reassign ? 1 : 0;
-    if (e->st_reassign >= 0 && (n != e->st_n || hop != e->st_hop || reassign != e->st_reassign || e->st_mode != 2))
-        return fail(e, EMSPEC_ERR_STATE, "fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
-    const int64_t expect = emspec_push_columns(e, count, n, hop, reassign);
-    if ((out_db || out_rgba) && expect > max_columns)
-        return fail(e, EMSPEC_ERR_INVALID_ARG, "output holds fewer columns than this block completes (" +
-                                                   std::to_string(expect) + "); size it with emspec_push_columns()");
-    HIPCHK(e, hipSetDevice(e->device));
-    const int R = e->cfg.rows;
-    const size_t cap = (size_t)n + (size_t)(kPushFrames - 1) * hop;   // samples one launch can see
-    if (e->st_reassign < 0) {
-        const int D = latency(n, hop, reassign);
-        const int W = 2 * D + kPushFrames;
-        if ((rc = grow(e, (void**)&e->d_ring, &e->ring_bytes, (size_t)(W + 1) * R * 8))) return rc;
-        for (int b = 0; b < 2; ++b)
-            if ((rc = grow(e, (void**)&e->d_sbuf[b], &e->sbuf_bytes[b], cap * 4))) return rc;
-        if ((rc = grow(e, (void**)&e->d_pushdb, &e->pushdb_bytes, (size_t)kPushFrames * R * 4))) return rc;
-        if ((rc = grow(e, (void**)&e->d_pushrgba, &e->pushrgba_bytes, (size_t)kPushFrames * R * 4))) return rc;
-        if (!e->d_coldb) HIPCHK(e, hipMalloc(&e->d_coldb, (size_t)4096 * 4));
-        if (!e->d_colrgba) HIPCHK(e, hipMalloc(&e->d_colrgba, (size_t)4096 * 4));
-        HIPCHK(e, hipMemsetAsync(e->d_ring, 0, (size_t)(W + 1) * R * 8, e->stream));
-        e->st_n = n; e->st_hop = hop; e->st_reassign = reassign; e->st_D = D; e->st_W = W; e->st_mode = 2;
-        e->st_have = 0; e->st_cur = 0;
-    }
-    Plan* p;
-    if ((rc = get_plan(e, n, &p))) return rc;
-    const PlanDev pd = plan_dev(e, *p, hop, reassign);
-    const DbMap m = db_map(e, n);
-    const bool exact = e->exact();
-    const ExactPlanDev xpd = exact ? exact_plan_dev(e, *p, hop, reassign) : ExactPlanDev{};
-    const ExactDbMap xm = exact ? exact_db_map(e, n, xpd) : ExactDbMap{};
-    const size_t cellb = exact ? 8 : 4;
-    const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
-    if (post && !e->d_pstate) {
-        HIPCHK(e, hipMalloc(&e->d_pstate, (size_t)(4096 + 4) * 4));
-        HIPCHK(e, hipMemsetAsync(e->d_pstate, 0, (size_t)(4096 + 4) * 4, e->stream));
-    }
-    const int D = e->st_D, W = e->st_W;
-    int64_t produced = 0, first = -1;
-    // A block that completes no frame (an audio worklet hands over 128 samples at a time) only joins the host-side
-    // pending samples: no copy, no launch, no synchronisation until a frame is due.
-    if (frames_after(e->st_have + (int64_t)e->st_pending.size() + count, n, hop) == 0) {
-        e->st_pending.insert(e->st_pending.end(), samples, samples + count);
-        if (out_count) *out_count = 0;
-        if (out_first_column) *out_first_column = -1;
-        return EMSPEC_OK;
-    }
-    auto feed = [&](const float* src, int64_t cnt) -> int {
-    int64_t used = 0;
-    while (used < cnt) {
-        const int64_t take = std::min<int64_t>(cnt - used, (int64_t)cap - e->st_have);
-        float* buf = e->d_sbuf[e->st_cur];
-        HIPCHK(e, hipMemcpyAsync(buf + e->st_have, src + used, (size_t)take * 4, hipMemcpyHostToDevice, e->stream));
-        used += take;
-        e->st_have += take;
-        const int64_t M = frames_after(e->st_have, n, hop);   // <= kPushFrames by the size of the buffer
-        if (M == 0) continue;
-        const int64_t j0 = e->st_fed;
-        FrameSinks sk;
-        sk.hist = e->d_ring;
-        sk.hist_slots = W;
-        sk.total_cols = INT64_MAX;
-        sk.ring = 1;
-        sk.col_offset = j0;   // buffered sample 0 is the first sample of absolute frame j0
-        if (exact) {
-            ExactSinks xs;
-            xs.hist = reinterpret_cast<unsigned long long*>(e->d_ring);
-            xs.hist_slots = W; xs.total_cols = INT64_MAX; xs.ring = 1; xs.col_offset = j0;
-            HIPCHK(e, launch_exact_frames(n, xpd, buf, e->st_have, 1, 0, M, xs, e->stream));
-        } else
-        HIPCHK(e, launch_frames(n, pd, buf, e->st_have, 1, 0, M, sk, e->stream));
-        // frames j0..j0+M-1 complete columns j0-D .. j0+M-1-D
-        const int64_t c0 = std::max<int64_t>(j0 - D, 0), c1 = j0 + M - D;   // [c0, c1)
-        for (int64_t c = c0; c < c1;) {
-            const int64_t slot = c % W;
-            const int64_t run = std::min<int64_t>(c1 - c, W - slot);        // contiguous slots before the ring wraps
-            float* cells = reinterpret_cast<float*>(reinterpret_cast<char*>(e->d_ring) + (size_t)slot * R * cellb);
-            float* ddb = e->d_pushdb + (size_t)(c - c0) * R;
-            uint8_t* drg = e->d_pushrgba + (size_t)(c - c0) * R * 4;
-            if (exact)
-                HIPCHK(e, launch_exact_finalize(reinterpret_cast<const unsigned long long*>(cells), run * R, xm, e->d_lut,
-                                                (out_db || post) ? ddb : nullptr, (out_rgba && !post) ? drg : nullptr, nullptr, e->stream));
-            else
-            HIPCHK(e, launch_finalize(cells, run * R, m, e->d_lut, (out_db || post) ? ddb : nullptr,
-                                      (out_rgba && !post) ? drg : nullptr, nullptr, e->stream));
-            HIPCHK(e, hipMemsetAsync(cells, 0, (size_t)run * R * cellb, e->stream));
-            c += run;
-        }
-        const int64_t nc = c1 > c0 ? c1 - c0 : 0;
-        if (post)
-            for (int64_t i = 0; i < nc; ++i)   // AGC and smoothing carry state from column to column
-                HIPCHK(e, launch_post_column(e->d_pushdb + (size_t)i * R, R, e->smoothing, e->agc, e->cfg.db_top, m, e->d_lut,
-                                             out_rgba ? e->d_pushrgba + (size_t)i * R * 4 : nullptr, e->d_pstate,
-                                             e->d_pstate + 4, e->stream));
-        if (nc > 0) {
-            if (first < 0) first = c0;
-            if (out_db) HIPCHK(e, hipMemcpyAsync(out_db + (size_t)produced * R, e->d_pushdb, (size_t)nc * R * 4, hipMemcpyDeviceToHost, e->stream));
-            if (out_rgba) HIPCHK(e, hipMemcpyAsync(out_rgba + (size_t)produced * R * 4, e->d_pushrgba, (size_t)nc * R * 4, hipMemcpyDeviceToHost, e->stream));
-            produced += nc;
-            e->st_emitted = c1;
-        }
-        // keep the samples later frames still need: everything from the start of frame j0+M
-        const int64_t keep = e->st_have - M * hop;
-        float* other = e->d_sbuf[e->st_cur ^ 1];
-        if (keep > 0) HIPCHK(e, hipMemcpyAsync(other, buf + M * hop, (size_t)keep * 4, hipMemcpyDeviceToDevice, e->stream));
-        e->st_cur ^= 1;
-        e->st_have = keep;
-        e->st_fed = j0 + M;
-    }
-    return EMSPEC_OK;
-    };
-    // A failure inside feed() leaves copies from `samples` / into the outputs in flight and the stream position half
-    // advanced: drain the stream (the buffers are only borrowed for this call) and drop the stream state, so the
-    // caller restarts from emspec_reset() semantics instead of silently re-feeding the pending samples.
-    auto abandon = [&](int code) {
-        const std::string msg = e->err;
-        (void)hipStreamSynchronize(e->stream);
-        (void)emspec_reset(e);
-        e->err = msg + " (stream state was reset)";
-        return code;
-    };
-    if (!e->st_pending.empty() && (rc = feed(e->st_pending.data(), (int64_t)e->st_pending.size()))) return abandon(rc);
-    if ((rc = feed(samples, count))) return abandon(rc);
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return abandon(fail(e, EMSPEC_ERR_HIP, "hipStreamSynchronize failed"));
-    e->st_pending.clear();   // only now: its upload above was asynchronous
-    if (out_count) *out_count = produced;
-    if (out_first_column) *out_first_column = first;
-    return EMSPEC_OK;
-}
-
-int emspec_column_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba, int32_t rows, int64_t* out_column) {
-    if (!e) return EMSPEC_ERR_INVALID_ARG;
-    if (rows != e->cfg.rows) return fail(e, EMSPEC_ERR_INVALID_ARG, "rows does not match the engine configuration");
-    if (e->st_reassign < 0 || e->st_emitted >= e->st_fed) return fail(e, EMSPEC_ERR_STATE, "no pending column");
-    HIPCHK(e, hipSetDevice(e->device));
-    const int64_t c = e->st_emitted;
-    if (out_column) *out_column = c;
-    int rc = emit_column(e, c, out_db, out_rgba);
-    if (rc) return rc;
-    e->st_emitted = c + 1;
-    return EMSPEC_OK;
-}
+// (the streaming calls - emspec_column, emspec_column_flush, emspec_push_samples, emspec_push_columns and the live multi-stream
+// session - live in emspec_live.cpp)
 
 }  // extern "C"

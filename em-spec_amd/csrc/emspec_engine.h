@@ -58,7 +58,7 @@ DbMap db_map(const emspec_engine* e, int n);
 bool host_pinned(const void* p);   // p is null or page-locked host memory the device can address
 void live_destroy(emspec_engine* e);   // emspec_live.cpp: called by emspec_destroy
 void live_reset(emspec_engine* e);     // drops the live session's stream state (emspec_reset); buffers are kept
-bool live_active(const emspec_engine* e);
+bool live_pending(const emspec_engine* e);   // some stream of either session has fed frames whose columns were not emitted yet
 }  // namespace emspec
 
 struct emspec_engine {
@@ -88,37 +88,14 @@ struct emspec_engine {
     bool xlow_used = false;
     char* d_stage = nullptr;
     size_t stage_bytes = 0;
-    // streaming state
-    int st_n = 0, st_hop = 0, st_reassign = -1, st_D = 0;
-    int st_W = 0;             // ring slots (2D+1 per-frame mode, 2D+kPushFrames sample mode); slot st_W is the empty column
-    int st_mode = 0;          // 0 idle, 1 per-frame (emspec_column), 2 per-sample-block (emspec_push_samples)
-    int64_t st_have = 0;      // sample mode: samples buffered in d_sbuf[st_cur], first one is sample st_fed*hop
-    int st_cur = 0;
-    std::vector<float> st_pending;   // sample mode: samples received since the last upload that complete no frame yet
-    float* d_sbuf[2] = {nullptr, nullptr};
-    size_t sbuf_bytes[2] = {0, 0};
-    float* d_pushdb = nullptr; size_t pushdb_bytes = 0;
-    uint8_t* d_pushrgba = nullptr; size_t pushrgba_bytes = 0;
-    int64_t st_fed = 0;       // frames fed so far
-    int64_t st_emitted = 0;   // columns emitted so far (flush included)
-    float* d_ring = nullptr;  // [W+1][rows]; slot W stays zero (the empty column)
-    size_t ring_bytes = 0;
-    float* d_frame = nullptr;
-    size_t frame_bytes = 0;
-    // per-frame streaming call without DMA: page-locked, device-visible host buffers the kernel reads the
-    // frame from and writes the finished column to (one launch + one sync per call)
-    float* h_frame = nullptr; size_t h_frame_bytes = 0;
-    float* h_coldb = nullptr;
-    uint8_t* h_colrgba = nullptr;
-    float* d_coldb = nullptr;
-    uint8_t* d_colrgba = nullptr;
     // display post-process (emspec_set_display)
     float smoothing = 0.0f, agc = 0.0f;
     float* d_raw = nullptr; size_t raw_bytes = 0;      // raw dB columns of a batch
     float* d_post = nullptr; size_t post_bytes = 0;    // post-processed dB when the caller wants none
     float* d_peak = nullptr; size_t peak_bytes = 0;    // column peaks + gains
-    float* d_pstate = nullptr;                         // streaming: [0]=AGC level, [1]=initialised, [2..]=previous column
-    emspec::LiveState live;   // live multi-stream streaming (emspec_live.cpp)
+    // streaming (emspec_live.cpp): the live multi-stream session, and the single-stream calls' own (emspec_column,
+    // emspec_push_samples: the same machinery with one stream); independent of each other
+    emspec::LiveState live, one;
     // multi-GPU gather of finished columns (emspec_comm.cpp); opaque here so this header needs no rccl.h
     struct emspec_comm_state* comm = nullptr;
 };

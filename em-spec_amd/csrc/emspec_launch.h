@@ -33,6 +33,7 @@ struct LiveSinks {
     uint32_t* out_rgba = nullptr;          // [S][out_cols][rows] RGBA8, or null
     int out_cols = 0;
     int empty_col = 0;                     // per-frame form: a frame that completes no column yet emits the empty column
+    int defer_finalize = 0;                // the frame kernel only scatters; live_finalize_kernel (one workgroup per column) follows
     const uint32_t* lut = nullptr;
 #ifdef EMSPEC_DIAG
     unsigned long long* stamps = nullptr;  // [S][8] 100 MHz wall-clock stamps of each stream's first workgroup (tools/live_phases.py)
@@ -146,8 +147,9 @@ hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_t
 // live multi-stream calls (live_launch.hip.inc): flush of pending columns, display post-process of a launch's columns.
 // The frame launches themselves go through launch_frames / launch_exact_frames with sinks.live set and
 // nframes = (largest per-stream frame count) + 1.
+// (ncol: the largest number of columns any stream emits - grid (ncol, S), one workgroup per column)
 hipError_t launch_live_flush(bool exact, const LiveSinks& lv, void* cells, int slots, int rows, int D, const DbMap& m,
-                             const ExactDbMap& xm, int S, hipStream_t st);
+                             const ExactDbMap& xm, int S, int ncol, hipStream_t st);
 hipError_t launch_live_post(const LiveSinks& lv, const float* raw, int rows, int D, float sm, float agc, float db_top,
                             const DbMap& dm, float* pstate, int S, hipStream_t st);
 // the gather's wire image (pack.hip.inc)

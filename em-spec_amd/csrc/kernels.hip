@@ -310,8 +310,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         const int bwm = natpos<LOG2N>((1 - t) & (T - 1)) + T * (16 - (t >= 2 ? 1 : 0));
         const int bw0 = natpos<LOG2N>((0 - t) & (T - 1)) + T * (16 - (t >= 1 ? 1 : 0));
         const int bwp = natpos<LOG2N>(T - 1 - t) + T * 15;
-        // (the live form is latency-bound - one wave per SIMD - and overlaps the bins' LDS round trips instead)
-        constexpr int BU = SINK == 3 ? 7 : EMSPEC_BINS_UNROLL;
+        // (the live and streaming forms are latency-bound - one wave per SIMD - and overlap the bins' LDS round trips instead)
+        constexpr int BU = (SINK == 3 || SINK == 0) ? 7 : EMSPEC_BINS_UNROLL;   // (SINK 0: the streaming calls, a frame or a few per launch)
 #pragma unroll BU
         for (int i = 1; i < 8; ++i)
             do_bin(t + T * i, bzm + T * i, bz0 + T * i, bzp + T * i, bwm - T * i, bw0 - T * i, bwp - T * i);
@@ -335,12 +335,25 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         __syncthreads();
         const int64_t slot = sk.fin_col >= 0 ? sk.fin_col % sk.hist_slots : sk.hist_slots;
         float* cells = sk.hist + (size_t)slot * pl.rows;
-        for (int r = t; r < pl.rows; r += T) {
-            const float e = __hip_atomic_load(cells + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float d = cell_db(sk.fin_map, e);
-            if (sk.fin_db) sk.fin_db[r] = d;
-            if (sk.fin_rgba) sk.fin_rgba[r] = sk.fin_lut[cell_index(sk.fin_map, d)];
-            if (sk.fin_col >= 0) cells[r] = 0.0f;
+        // eight rows of a thread in flight at once: each load is a round trip to the memory side, and one per loop iteration
+        // made them serial (round 6: the live multi-stream kernel's finalize went from 9.8 to 2.3 us this way, live.hip.inc)
+        constexpr int FIN = 8;
+        for (int r0 = t; r0 < pl.rows; r0 += T * FIN) {
+            float e[FIN];
+#pragma unroll
+            for (int u = 0; u < FIN; ++u) {
+                const int r = r0 + u * T;
+                e[u] = r < pl.rows ? __hip_atomic_load(cells + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < FIN; ++u) {
+                const int r = r0 + u * T;
+                if (r >= pl.rows) break;
+                const float d = cell_db(sk.fin_map, e[u]);
+                if (sk.fin_db) sk.fin_db[r] = d;
+                if (sk.fin_rgba) sk.fin_rgba[r] = sk.fin_lut[cell_index(sk.fin_map, d)];
+                if (sk.fin_col >= 0) cells[r] = 0.0f;
+            }
         }
     }
 }

@@ -76,9 +76,9 @@ for j in range(20, 520):
     raw(e, small[j], 256, 64)
 dt_small = (time.perf_counter() - t0) / 500
 print(f"emspec_column through raw ctypes (no wrapper allocations): {dt_raw * 1e6:.1f} us per column at N = 4096; {dt_small * 1e6:.1f} us at N = 256 "
-      f"(= the fixed cost of one launch + one stream synchronisation + the two host copies; a hipGraph replay costs 10-16 us "
-      f"on this stack against 3-5 us for a direct launch - MI355X_MICROARCH.md 'graph-replay-floor' - so capturing this single "
-      f"launch cannot lower it)")
+      f"(N = 256: frame launch + the 256-thread finalize launch; = the fixed cost of launching + one stream synchronisation + "
+      f"the host copies; a hipGraph replay costs 10-16 us on this stack against 3-5 us for a direct launch - MI355X_MICROARCH.md "
+      f"'graph-replay-floor' - so capturing this single launch cannot lower it)")
 with emspec.Engine(mode=emspec.MODE_EXACT) as x:
     for j in range(20):
         raw(x, frames[j], n, hop)
@@ -86,7 +86,7 @@ with emspec.Engine(mode=emspec.MODE_EXACT) as x:
     for j in range(20, 520):
         raw(x, frames[j], n, hop)
     dt_x = (time.perf_counter() - t0) / 500
-print(f"emspec_column, EXACT mode (binary64, u64 ring; frame copy + two launches + column copy): {dt_x * 1e6:.1f} us per column")
+print(f"emspec_column, EXACT mode (binary64, u64 ring in HBM; one launch, as the float32 mode since round 6): {dt_x * 1e6:.1f} us per column")
 for blk in (128, 512, 2048, 16384, 131072):
     e.reset()
     e.push_samples(fr[:n + 16 * hop], n, hop, True)
