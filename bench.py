@@ -1110,15 +1110,19 @@ def visible_gpus():
     import glob
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     count = 0
-    try:
-        for f in nodes:
-            for ln in open(f):
-                k, _, v = ln.partition(" ")
-                if k == "simd_count" and int(v) > 0:
-                    count += 1
-                    break
-    except OSError:
-        nodes = []
+    for f in nodes:
+        # a container lists every GPU of the host here while its device cgroup admits only some: a node whose properties
+        # cannot be read, or whose render node cannot be opened, is not ours
+        try:
+            props = dict(ln.split(None, 1) for ln in open(f) if " " in ln.strip())
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                   # a CPU node
+            minor = int(props.get("drm_render_minor", "-1"))
+        except (OSError, ValueError):
+            continue
+        if minor >= 0 and not os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK):
+            continue
+        count += 1
     if not nodes:
         return torch.cuda.device_count()
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
