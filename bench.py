@@ -1151,6 +1151,8 @@ def spawn_ranks(argv):
         return None
     if known.backend == "nccl" and not known.dry_run_ranks:
         have = visible_gpus()
+        if have < known.gpus:          # (sysfs may hide what the runtime can open: ask torch before refusing - counting devices does not initialise HIP on this image)
+            have = max(have, torch.cuda.device_count())
         if have < known.gpus:          # RCCL refuses two ranks on one device: say so in a line the driver can parse
             print(json.dumps({"error": f"--gpus {known.gpus} with --backend nccl needs {known.gpus} visible GPUs, found {have}",
                               "n_gpus": known.gpus, "visible_gpus": have, "metric": None, "value": None}), flush=True)

@@ -14,6 +14,7 @@
 #                    python tools/profile_json.py gpurun_out/<tag>_paritydump <tag> paritydump 65296 --last 20
 #                    python tools/profile_json.py gpurun_out/<tag>_exact64 <tag> exact64 1047616
 #                    python tools/profile_json.py gpurun_out/<tag>_exact_n16384 <tag> exact_n16384 522304 --all-kernels
+#                    python tools/profile_json.py gpurun_out/<tag>_exact_n1024 <tag> exact_n1024 1048384
 #                    cp gpurun_out/<tag>_*.txt profiles/   and commit;
 set -e
 tag=${1:-r02}
@@ -36,6 +37,8 @@ bash tools/profile_workload.sh ${tag}_exact64 --mode exact --no-configs > gpurun
 echo "exact64 profiled"
 bash tools/profile_workload.sh ${tag}_exact_n16384 --mode exact --workload n16384 > gpurun_out/prof_exact_n16384.log 2>&1
 echo "exact_n16384 profiled"
+bash tools/profile_workload.sh ${tag}_exact_n1024 --mode exact --workload n1024 > gpurun_out/prof_exact_n1024.log 2>&1
+echo "exact_n1024 profiled"
 cd "$R"
 timeout -k 10 200 python tools/phase_cycles.py 64 waves > gpurun_out/${tag}_batch64_phase_cycles.txt 2>&1
 timeout -k 10 200 python tools/phase_cycles_n16384.py > gpurun_out/${tag}_n16384_phase_cycles.txt 2>&1 || true
@@ -44,6 +47,11 @@ timeout -k 10 200 python tools/kernel_clock.py > gpurun_out/${tag}_kernel_clock.
 timeout -k 10 200 python tools/gather_cost.py > gpurun_out/${tag}_gather_cost.txt 2>&1 || true
 timeout -k 10 300 python tools/host_rates.py > gpurun_out/${tag}_host_api_rate.txt 2>&1 || true
 timeout -k 10 300 python tools/host_pipeline_rates.py > gpurun_out/${tag}_host_pipeline_rate.txt 2>&1 || true
+# round 6: the live multi-stream entries (per-call host time of every variant; the frame kernel's phases), EXACT at the small sizes
+timeout -k 10 300 python tools/live_rate.py 64 400 > gpurun_out/${tag}_live_rate.txt 2>&1 || true
+timeout -k 10 200 python tools/live_phases.py 64 200 > gpurun_out/${tag}_live_phases.txt 2>&1 || true
+timeout -k 10 300 python tools/exact_small_rate.py > gpurun_out/${tag}_exact_small_rate.txt 2>&1 || true
+(cd /tmp && /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/launch_sync "$R/tools/ubench/launch_sync.hip" > /dev/null 2>&1 && timeout -k 10 60 /tmp/launch_sync > "$R/gpurun_out/${tag}_launch_sync.txt" 2>&1) || true
 fi
 if [[ $part == *c* ]]; then
 # the bench lines, on the SAME box as the profiles they quote (tests/test_bench_helpers.py holds every profile's median
