@@ -54,6 +54,16 @@ timeout -k 10 300 python tools/exact_small_rate.py > gpurun_out/${tag}_exact_sma
 (cd /tmp && /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/launch_sync "$R/tools/ubench/launch_sync.hip" > /dev/null 2>&1 && timeout -k 10 60 /tmp/launch_sync > "$R/gpurun_out/${tag}_launch_sync.txt" 2>&1) || true
 fi
 if [[ $part == *c* ]]; then
+# the bench lines quote a profile's counters only when profiles/<tag>_<workload>.json carries the library's sources sha: condense
+# this call's profiles HERE, on the box, before the lines are taken (the same command is repeated on the merged gpurun_out/
+# afterwards - the result is identical - and THAT copy is committed); one call then does for the whole set
+cd "$R"
+for spec in "batch64 batch64 1047616" "n16384 n16384 522304" "paritydump paritydump 65296 --last 20" "exact64 exact64 1047616" \
+            "exact_n16384 exact_n16384 522304 --all-kernels" "exact_n1024 exact_n1024 1048384"; do
+  set -- $spec
+  d=$1; wl=$2; cols=$3; shift 3
+  [ -d gpurun_out/${tag}_$d ] && python tools/profile_json.py gpurun_out/${tag}_$d $tag $wl $cols "$@" > /dev/null 2>> gpurun_out/profile_json.err
+done
 # the bench lines, on the SAME box as the profiles they quote (tests/test_bench_helpers.py holds every profile's median
 # duration to <= 1.02 x the line's kernel time: between boxes the clocks differ by more than that)
 cd "$R"
