@@ -55,7 +55,8 @@ void live_forget(LiveState& lv) {
 int live_open(emspec_engine* e, LiveState& lv, int S, int n, int hop, int reassign, int form) {
     const int R = e->cfg.rows;
     const int D = latency(n, hop, reassign);
-    const int mmax = form == 1 ? 1 : live_frames_per_launch(S);
+    // (a staging block of at most 2^17 samples per stream: at a large hop fewer frames per launch instead of megabytes pinned)
+    const int mmax = form == 1 ? 1 : std::max(1, std::min(live_frames_per_launch(S), (1 << 17) / hop));
     const int slots = 2 * D + mmax;
     const int64_t cap = form == 1 ? n : (int64_t)mmax * hop;
     int ring = 1;

@@ -281,7 +281,7 @@ def test_exact_mode_guards(xengine, engine):
     assert xengine.fused(4096, 256, True) and xengine.fused(4096, 1024, False) and not xengine.fused(4096, 128, True)
     assert not xengine.fused(16384, 512, True) and not xengine.fused(8192, 512, True)
     assert xengine.fused(1024, 256, True) and xengine.fused(2048, 256, True) and xengine.fused(2048, 128, True)
-    assert not xengine.fused(1024, 64, True)
+    assert xengine.fused(1024, 64, True) and not xengine.fused(1024, 32, True)
     assert xengine.mode == emspec.MODE_EXACT and engine.mode == emspec.MODE_FAST
     with pytest.raises(emspec.EmspecError):
         emspec.Engine(mode=7)
@@ -390,8 +390,8 @@ SMALL_FUSED_CASES = [  # n, hop, frames, S, reassign, rows, seglen, engine setti
     (1024, 256, 3, 2, True, 1024, 0, {}),         # fewer frames than one block
     (1024, 256, 1, 1, True, 1024, 0, {}),
     (1024, 128, 200, 2, True, 1024, 0, {}),       # D = 4
-    (1024, 64, 150, 1, True, 1024, 0, {}),        # D = 8: 24 slots, 604 low rows - more low quads than the team has threads: records path
-    (1024, 96, 150, 1, True, 1024, 0, {}),        # D = 6: 20 slots, 520 low rows: records path too
+    (1024, 64, 150, 1, True, 1024, 0, {}),        # D = 8: 24 slots, 604 low rows - more low quads per block than the team has threads
+    (1024, 96, 150, 2, True, 1024, 40, {}),       # D = 6: 20 slots, 520 low rows
     (1024, 100, 90, 1, True, 1024, 0, {}),        # a hop that is no power of two
     (1024, 256, 120, 2, False, 1024, 48, {}),     # reassignment off: D = 0, the branchy per-bin core
     (1024, 256, 90, 2, True, 512, 0, {}),         # the whole ring in LDS (no low rows)
@@ -415,8 +415,7 @@ def test_exact_fused_small_sizes(n, hop, frames, S, reassign, rows, seglen, kw, 
         monkeypatch.setenv("EMSPEC_SEGLEN", str(seglen))
     pcm = _pcm(n, hop, frames, S=S, extra=5)
     with emspec.Engine(mode=emspec.MODE_EXACT, diag=True, rows=rows, **kw) as e:
-        # (N = 1024 at hop < 128: more than 512 low rows - more low quads per block than the team has threads - records path)
-        assert e.fused(n, hop, reassign) == (n == 2048 or hop >= 128)
+        assert e.fused(n, hop, reassign)
         out = e.batch(pcm, n, hop, reassign, want=("db", "rgba", "index"))
         e.device_status()
     odb, orgba, oidx, _ = O.batch_exact(O.make_cfg(n, hop, reassign, rows=rows, **kw), pcm)
