@@ -55,14 +55,8 @@ struct FrameSinks {
     int64_t total_cols = 0;    // valid absolute columns are [0,total_cols)
     int32_t ring = 0;          // !=0: slot = col % hist_slots (streaming ring), else slot = col
     int64_t col_offset = 0;    // added to the frame index to get its absolute column (streaming)
-    // streaming, one frame per launch: the frame's own workgroup also emits the column this frame completes
-    // (fin_col, or the empty column when < 0) from the ring and clears its slot - one launch instead of three
-    float* fin_db = nullptr;          // [rows] dB, or null
-    uint32_t* fin_rgba = nullptr;     // [rows] RGBA8, or null
-    const uint32_t* fin_lut = nullptr;
-    int64_t fin_col = -1;
-    DbMap fin_map{};
     LiveSinks live{};                 // live multi-stream launch (uses hist / hist_slots / fin_map)
+    DbMap fin_map{};                  // ... its "dB + colour" stage
 };
 
 // Where the exact-mode frame kernels send their per-bin results (exact.hip.inc)
@@ -111,8 +105,6 @@ hipError_t launch_exact_fused_lr(int n, const ExactPlanDev& pl, const ExactDbMap
                                  int64_t L, int S, int64_t C, int rl, unsigned long long* low, size_t low_bytes, float* db,
                                  uint8_t* rgba, uint8_t* index, hipStream_t st, unsigned long long* stamps = nullptr,
                                  int64_t* stamp_groups = nullptr);
-hipError_t launch_exact_finalize(const unsigned long long* cells, int64_t ncells, const ExactDbMap& m, const uint8_t* lut,
-                                 float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
 
 // the device word a kernel raises when a bounded wait times out (kernels.hip: g_kernel_error); -1 if it cannot be read
 int read_kernel_error(bool clear);
@@ -128,12 +120,8 @@ hipError_t launch_frames(int n, const PlanDev& pl, const float* pcm, int64_t L, 
 hipError_t launch_tile_scatter(const uint2* records, int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                                int S, int64_t C, float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
 
-// hist cells -> dB / RGBA / palette index (any output may be null). ncells % 4 == 0.
-hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, const uint8_t* lut,
-                           float* db, uint8_t* rgba, uint8_t* index, hipStream_t st);
-
 // Fused batch path (LDS column ring): returns hipErrorNotSupported when (n,hop,rows)
-// has no fused specialisation; the caller then uses launch_frames + launch_finalize.
+// has no fused specialisation; the caller then uses launch_frames + launch_tile_scatter.
 hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t* lut,
                         const float* pcm, int64_t L, int S, int64_t total_cols,
                         float* db, uint8_t* rgba, uint8_t* index, hipStream_t st,
@@ -142,8 +130,6 @@ hipError_t launch_fused(int n, const PlanDev& pl, const DbMap& m, const uint8_t*
 hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uint8_t* index, int S, int64_t C, int R,
                               float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut, float* peak,
                               float* gain, hipStream_t st);
-hipError_t launch_post_column(float* col, int R, float sm, float agc, float db_top, const DbMap& dm, const uint8_t* lut,
-                              uint8_t* rgba, float* state, float* yprev, hipStream_t st);
 // live multi-stream calls (live_launch.hip.inc): flush of pending columns, display post-process of a launch's columns.
 // The frame launches themselves go through launch_frames / launch_exact_frames with sinks.live set and
 // nframes = (largest per-stream frame count) + 1.

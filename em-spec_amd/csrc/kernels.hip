@@ -323,39 +323,6 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         live_stamp(sk.live, s, (int)f, 6);
         return;
     }
-    if constexpr (SINK != 0) return;
-    if (sk.fin_db || sk.fin_rgba) {
-        // streaming call (one frame, one workgroup): every earlier frame scattered in an earlier launch and this
-        // frame's atomics are ordered by the fence + barrier, so column fin_col is complete: emit it and clear its
-        // ring slot here.  Slot hist_slots is the always-empty column (used while the ring primes).
-        // (A WORKGROUP-scope fence: the cells are read below by this same workgroup with agent-scope atomic loads, i.e.
-        // from the L2 the atomics were performed in; the agent-scope fence that stood here also wrote the L2 back -
-        // `buffer_wbl2 sc1` - which the end of the kernel does anyway: ~2 us of the call.)
-        __threadfence_block();
-        __syncthreads();
-        const int64_t slot = sk.fin_col >= 0 ? sk.fin_col % sk.hist_slots : sk.hist_slots;
-        float* cells = sk.hist + (size_t)slot * pl.rows;
-        // eight rows of a thread in flight at once: each load is a round trip to the memory side, and one per loop iteration
-        // made them serial (round 6: the live multi-stream kernel's finalize went from 9.8 to 2.3 us this way, live.hip.inc)
-        constexpr int FIN = 8;
-        for (int r0 = t; r0 < pl.rows; r0 += T * FIN) {
-            float e[FIN];
-#pragma unroll
-            for (int u = 0; u < FIN; ++u) {
-                const int r = r0 + u * T;
-                e[u] = r < pl.rows ? __hip_atomic_load(cells + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < FIN; ++u) {
-                const int r = r0 + u * T;
-                if (r >= pl.rows) break;
-                const float d = cell_db(sk.fin_map, e[u]);
-                if (sk.fin_db) sk.fin_db[r] = d;
-                if (sk.fin_rgba) sk.fin_rgba[r] = sk.fin_lut[cell_index(sk.fin_map, d)];
-                if (sk.fin_col >= 0) cells[r] = 0.0f;
-            }
-        }
-    }
 }
 
 bool supported_fft(int n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096 || n == 8192 || n == 16384; }
@@ -367,7 +334,7 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     const size_t lds = (size_t)(PaddedSize<N>::value + mid_tw_entries(LOG2N)) * sizeof(float2) + (size_t)(pl.rows + 1) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // the sink combination picks the build: dump only, records only, or the run-time form
-    const bool plain = !sk.hist && !sk.fin_db && !sk.fin_rgba;
+    const bool plain = !sk.hist;
     const int sink = sk.live.streams ? 3 : (plain && sk.power && !sk.records) ? 1 : ((plain && sk.records && !sk.power) ? 2 : 0);
     const bool fastc = sink != 0 && emspec_plan_is_fast(pl);
     const void* fn = sink == 1 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1>))
@@ -624,39 +591,6 @@ hipError_t launch_tile_scatter(const uint2* records, int n, const PlanDev& pl, c
     if (n >= 8192) return launch_tile_scatter_t<32>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
     if (n >= 2048) return launch_tile_scatter_t<8>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
     return launch_tile_scatter_t<4>(records, n, pl, m, lut, S, C, db, rgba, index, st, tile, lds);
-}
-
-// ---------------------------------------------------------------------------
-// finalize: 4 cells per thread, 16-byte loads/stores, grid-stride.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void finalize_kernel(const float4* __restrict__ hist, int64_t nquads, DbMap m,
-                                                       const uint32_t* __restrict__ lut, float4* __restrict__ db,
-                                                       uint4* __restrict__ rgba, uint32_t* __restrict__ index) {
-    __shared__ uint32_t slut[256];
-    slut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * 256) {
-        const float4 e = hist[q];
-        const float d0 = cell_db(m, e.x), d1 = cell_db(m, e.y), d2 = cell_db(m, e.z), d3 = cell_db(m, e.w);
-        const int i0 = cell_index(m, d0), i1 = cell_index(m, d1), i2 = cell_index(m, d2), i3 = cell_index(m, d3);
-        if (db) db[q] = make_float4(d0, d1, d2, d3);
-        if (rgba) rgba[q] = make_uint4(slut[i0], slut[i1], slut[i2], slut[i3]);
-        if (index) index[q] = (uint32_t)i0 | ((uint32_t)i1 << 8) | ((uint32_t)i2 << 16) | ((uint32_t)i3 << 24);
-    }
-}
-
-hipError_t launch_finalize(const float* hist, int64_t ncells, const DbMap& m, const uint8_t* lut, float* db,
-                           uint8_t* rgba, uint8_t* index, hipStream_t st) {
-    if (ncells <= 0) return hipSuccess;
-    if (ncells % 4) return hipErrorInvalidValue;
-    const int64_t nquads = ncells / 4;
-    int64_t blocks = (nquads + 255) / 256;
-    if (blocks > 2048 * 4) blocks = 2048 * 4;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(hist), nquads, m, reinterpret_cast<const uint32_t*>(lut),
-                       reinterpret_cast<float4*>(db), reinterpret_cast<uint4*>(rgba),
-                       reinterpret_cast<uint32_t*>(index));
-    return hipGetLastError();
 }
 
 #ifdef EMSPEC_DIAG
