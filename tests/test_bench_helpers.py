@@ -97,7 +97,11 @@ def test_profile_durations_do_not_exceed_the_bench_lines():
         p = json.load(open(f))
         if p.get("sources_sha") != sha:
             continue                      # taken on other kernels than the line: not comparable
-        assert p["rocprof_median_ms"] <= 1.02 * ms, (wl, p["rocprof_median_ms"], ms)
+        # (a workload of many dispatches per step - EXACT off the one-kernel sizes: 77 of them - is summarised as the SUM of its
+        # dispatches' durations under the tracer, which runs a step's kernels one by one; the line's figure is the HIP-event wall
+        # time of the step, in which the tail of one kernel overlaps the head of the next: 3 % for those)
+        tol = 1.03 if p.get("kernel_split") else 1.02
+        assert p["rocprof_median_ms"] <= tol * ms, (wl, p["rocprof_median_ms"], ms)
         checked += 1
     if tag >= "r05":
         assert checked >= 3, (tag, checked, sorted(pairs))
