@@ -30,7 +30,7 @@ class Engine {
   /** Page-locked Float32Array / Uint8Array views for the live calls, (re)made when the shape changes. */
   _liveBlocks(fftSize, wantRgba) {
     const S = this.streams, R = this.rows;
-    if (!this.frames || this.frames.length !== S * fftSize) this.frames = new Float32Array(native.allocPinned(4 * S * fftSize));
+    if (fftSize > 0 && (!this.frames || this.frames.length !== S * fftSize)) this.frames = new Float32Array(native.allocPinned(4 * S * fftSize));
     if (!this.columnsDb) this.columnsDb = new Float32Array(native.allocPinned(4 * S * R));
     if (wantRgba && !this.columnsRgba) this.columnsRgba = new Uint8Array(native.allocPinned(4 * S * R));
   }
@@ -60,7 +60,7 @@ class Engine {
   /** Every stream that still has pending columns emits its next one (others: the empty column, columnIndex -1);
    *  throws EMSPEC_ERR_STATE when no stream has any.  Returns engine.columnsDb. */
   flushColumns(wantRgba = false) {
-    this._liveBlocks(this.frames ? this.frames.length / this.streams : 0, wantRgba);
+    this._liveBlocks(0, wantRgba);   // (the column blocks only: a session fed by sample blocks never made a frame block)
     native.columnsFlush(this._h, this.columnsDb, wantRgba ? this.columnsRgba : undefined, this.columnIndex);
     return this.columnsDb;
   }

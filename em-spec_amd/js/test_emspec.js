@@ -260,6 +260,12 @@ async function checkLive() {
   const one = em.createEngine({ exact: true });
   one.computeColumns(pcm, S, L, fftSize, hop, true, { db: batch });
   one.destroy();
+  const batchShort = new Float32Array(10 * R);   // stream 0 cut after ten frames (its last D columns differ from the long run's)
+  {
+    const o2 = em.createEngine({ exact: true });
+    o2.computeColumns(pcm.subarray(0, fftSize + 9 * hop), 1, fftSize + 9 * hop, fftSize, hop, true, { db: batchShort });
+    o2.destroy();
+  }
   const got = new Float32Array(S * frames * R);
   const take = (db) => {
     for (let s = 0; s < S; s++) if (eng.columnIndex[s] >= 0) got.set(db.subarray(s * R, (s + 1) * R), (s * frames + eng.columnIndex[s]) * R);
@@ -315,6 +321,19 @@ async function checkLive() {
   try { eng.computeSpectrogramColumns(eng.frames, fftSize, hop, true); } catch (e) { threw = e.code === 'EMSPEC_ERR_STATE'; }
   if (!threw) throw new Error('live: mixing frame and sample feeding must throw EMSPEC_ERR_STATE');
   eng.destroy();
+  // a session fed by sample blocks only: its pending columns drain through flushColumns (no frame block was ever made)
+  const eng2 = em.createEngine({ exact: true, streams: 2 });
+  const two = new Float32Array(2 * (fftSize + 9 * hop));
+  two.set(pcm.subarray(0, fftSize + 9 * hop), 0); two.set(pcm.subarray(L, L + fftSize + 9 * hop), fftSize + 9 * hop);
+  const r2 = eng2.pushSamplesMulti(two, fftSize, hop, true);
+  if (r2.counts[0] !== 10 - D || r2.counts[1] !== 10 - D) throw new Error('live push: ' + r2.counts[0] + ' columns from ten frames');
+  for (let k = 0; k < D; k++) {
+    const db = eng2.flushColumns();
+    const c = 10 - D + k;
+    if (eng2.columnIndex[0] !== c || eng2.columnIndex[1] !== c) throw new Error('live flush after sample blocks: column index');
+    for (let r = 0; r < R; r++) if (db[r] !== batchShort[c * R + r]) throw new Error('live flush after sample blocks: column ' + c + ' differs');
+  }
+  eng2.destroy();
   // module-level drop-in
   const cols = em.computeSpectrogramColumns(new Float32Array(3 * 1024), 1024, 256, false);
   if (cols.length !== 3 * 1024) throw new Error('module-level multi-stream call');
