@@ -106,9 +106,52 @@ int main(void) {
         CHECK(emspec_parity_dump(x, pcm, 1, L, n, hop, 1, 0, 1, fpw, fc, frw) == EMSPEC_ERR_STATE, "float32 dump accepted by an exact-mode engine");
         free(pw); free(cc); free(rr); free(qq);
     }
+    /* the live multi-stream session from plain C: three streams (the signal, half of it, silence) fed hop by hop through
+     * emspec_push_samples_multi from PAGE-LOCKED blocks (emspec_host_alloc: the kernel reads and writes them in place), one
+     * restarted half way; stream 0 must give the batch call's bits, the silent stream the floor everywhere */
+    {
+        const int S = 3;
+        float* blk = NULL; float* odb = NULL;
+        CHECK(emspec_host_alloc(sizeof(float) * S * hop, (void**)&blk) == EMSPEC_OK, "host_alloc");
+        CHECK(emspec_host_alloc(sizeof(float) * S * 1 * R, (void**)&odb) == EMSPEC_OK, "host_alloc");
+        int64_t counts[3], firsts[3], cols[3];
+        CHECK(emspec_live_streams(x) == 0, "a live session before the first call");
+        CHECK(emspec_reset_stream(x, 0) == EMSPEC_ERR_STATE, "reset_stream without a session");
+        /* prime with n - hop samples: no frame is complete, nothing is launched */
+        float* prime = (float*)malloc(sizeof(float) * S * (n - hop));
+        for (int s = 0; s < S; ++s) for (int i = 0; i < n - hop; ++i) prime[(size_t)s * (n - hop) + i] = s == 0 ? pcm[i] : (s == 1 ? 0.5f * pcm[i] : 0.0f);
+        CHECK(emspec_push_columns_multi(x, n - hop, n, hop, 1) == 0, "push_columns_multi");
+        CHECK(emspec_push_samples_multi(x, prime, S, n - hop, n - hop, n, hop, 1, NULL, NULL, R, 0, counts, firsts) == EMSPEC_OK, emspec_last_error(x));
+        CHECK(emspec_live_streams(x) == S && counts[0] == 0 && firsts[2] == -1, "priming block");
+        int restarted_at = -1;
+        for (int j = 0; j < frames; ++j) {
+            if (j == 25) { CHECK(emspec_reset_stream(x, 1) == EMSPEC_OK, emspec_last_error(x)); restarted_at = j; }
+            for (int i = 0; i < hop; ++i) {
+                const float v = pcm[(long)(n - hop) + (long)j * hop + i];
+                blk[i] = v; blk[hop + i] = 0.5f * v; blk[2 * hop + i] = 0.0f;
+            }
+            CHECK(emspec_push_samples_multi(x, blk, S, hop, hop, n, hop, 1, odb, NULL, R, 1, counts, firsts) == EMSPEC_OK, emspec_last_error(x));
+            CHECK(counts[0] == (j >= D ? 1 : 0) && counts[2] == counts[0], "live: columns per call");
+            if (j >= D) {
+                CHECK(firsts[0] == j - D, "live: column index");
+                CHECK(memcmp(odb, xdb + (size_t)(j - D) * R, sizeof(float) * R) == 0, "live: stream 0 differs from the batch bits");
+                for (int r = 0; r < R; ++r) CHECK(odb[(size_t)2 * R + r] == odb[(size_t)2 * R], "live: the silent stream is not flat");
+            }
+            if (restarted_at >= 0) CHECK(counts[1] == 0, "live: the restarted stream has no complete frame yet (it needs n samples)");
+        }
+        CHECK(emspec_columns(x, pcm, S, n, hop, 1, odb, NULL, R, cols) == EMSPEC_ERR_STATE, "feeding form changed mid-session");
+        for (int k = 0; k < D; ++k) {
+            CHECK(emspec_columns_flush(x, odb, NULL, R, cols) == EMSPEC_OK, emspec_last_error(x));
+            CHECK(cols[0] == frames - D + k && cols[1] == -1, "live flush: column indices");
+            CHECK(memcmp(odb, xdb + (size_t)cols[0] * R, sizeof(float) * R) == 0, "live flush: stream 0 differs from the batch bits");
+        }
+        CHECK(emspec_columns_flush(x, odb, NULL, R, cols) == EMSPEC_ERR_STATE, "live flush past the end");
+        CHECK(emspec_reset(x) == EMSPEC_OK && emspec_live_streams(x) == 0, "reset ends the live session");
+        emspec_host_free(blk); emspec_host_free(odb); free(prime);
+    }
     emspec_destroy(x);
     free(xdb); free(xdb2);
     free(pcm); free(db); free(rgba); free(col);
-    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells\n", worst, xworst);
+    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells; live multi-stream session (3 streams, page-locked blocks) == batch bits\n", worst, xworst);
     return 0;
 }
