@@ -84,6 +84,11 @@ int live_check(emspec_engine* e, const LiveState& lv, int S, int n, int hop, int
     if (S < 1 || S > 65535) return fail(e, EMSPEC_ERR_INVALID_ARG, "streams must be in 1..65535");
     if (lv.form != 0 && (S != lv.S || n != lv.n || hop != lv.hop || reassign != lv.reassign || form != lv.form))
         return fail(e, EMSPEC_ERR_STATE, "streams / fft size / hop / reassign / feeding mode changed mid-stream; call emspec_reset() first");
+    // A flush emits columns that later frames would still have added to: the stream is at its end.  Feeding it again would emit
+    // those columns a second time, holding only the new frames' energy.
+    for (int s = 0; s < lv.S; ++s)
+        if (lv.emitted[s] > std::max<int64_t>(lv.fed[s] - lv.D, 0))
+            return fail(e, EMSPEC_ERR_STATE, "stream " + std::to_string(s) + " was flushed: reset it (emspec_reset / emspec_reset_stream) before feeding it again");
     return EMSPEC_OK;
 }
 

@@ -191,8 +191,8 @@ __device__ __forceinline__ void fft_rest(float2* sm, const float2* stw, int t, c
     }
 }
 
-// SINK: which outputs are compiled in.  0 = whatever the FrameSinks say at run time (the streaming call: histogram
-// atomics + the finished column); 1 = the parity dump only; 2 = the records for the tile scatter only; 3 = a live
+// SINK: which outputs are compiled in.  0 = whatever the FrameSinks say at run time (not instantiated since round 6: the
+// streaming calls it served are the live form now); 1 = the parity dump only; 2 = the records for the tile scatter only; 3 = a live
 // multi-stream launch (live.hip.inc: per-stream frame counts, samples from the ring / the staging block, ring atomics,
 // the stream's last workgroup finalises).  With the
 // run-time form every bin re-tests five sink pointers and recomputes three 64-bit frame offsets on the scalar unit -
@@ -310,8 +310,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16) void frames_kernel(
         const int bwm = natpos<LOG2N>((1 - t) & (T - 1)) + T * (16 - (t >= 2 ? 1 : 0));
         const int bw0 = natpos<LOG2N>((0 - t) & (T - 1)) + T * (16 - (t >= 1 ? 1 : 0));
         const int bwp = natpos<LOG2N>(T - 1 - t) + T * 15;
-        // (the live and streaming forms are latency-bound - one wave per SIMD - and overlap the bins' LDS round trips instead)
-        constexpr int BU = (SINK == 3 || SINK == 0) ? 7 : EMSPEC_BINS_UNROLL;   // (SINK 0: the streaming calls, a frame or a few per launch)
+        // (the live form is latency-bound - one wave per SIMD - and overlaps the bins' LDS round trips instead)
+        constexpr int BU = SINK == 3 ? 7 : EMSPEC_BINS_UNROLL;
 #pragma unroll BU
         for (int i = 1; i < 8; ++i)
             do_bin(t + T * i, bzm + T * i, bz0 + T * i, bzp + T * i, bwm - T * i, bw0 - T * i, bwp - T * i);
@@ -336,11 +336,11 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     // the sink combination picks the build: dump only, records only, or the run-time form
     const bool plain = !sk.hist;
     const int sink = sk.live.streams ? 3 : (plain && sk.power && !sk.records) ? 1 : ((plain && sk.records && !sk.power) ? 2 : 0);
-    const bool fastc = sink != 0 && emspec_plan_is_fast(pl);
+    if (sink == 0) return hipErrorInvalidValue;   // (no caller mixes the sinks; the run-time form is not instantiated any more)
+    const bool fastc = emspec_plan_is_fast(pl);
     const void* fn = sink == 1 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 1>))
                    : sink == 2 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 2>))
-                   : sink == 3 ? (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3>))
-                               : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 0>);
+                               : (fastc ? reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3, true>) : reinterpret_cast<const void*>(&frames_kernel<LOG2N, 3>));
     if (lds > 64 * 1024) {
         const hipError_t e = allow_max_lds(fn);
         if (e != hipSuccess) return e;
@@ -354,8 +354,7 @@ static hipError_t launch_frames_t(const PlanDev& pl, const float* pcm, int64_t L
     else if (sink == 2 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 2, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     else if (sink == 2) hipLaunchKernelGGL((frames_kernel<LOG2N, 2>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     else if (sink == 3 && fastc) hipLaunchKernelGGL((frames_kernel<LOG2N, 3, true>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
-    else if (sink == 3) hipLaunchKernelGGL((frames_kernel<LOG2N, 3>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
-    else hipLaunchKernelGGL((frames_kernel<LOG2N, 0>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
+    else hipLaunchKernelGGL((frames_kernel<LOG2N, 3>), grid, block, lds, st, pl, pcm, L, frame0, nframes, sk);
     return hipGetLastError();
 }
 

@@ -201,7 +201,10 @@ int emspec_column(emspec_engine* e, const float* frame, int32_t n, int32_t hop,
                   int32_t rows, int64_t* out_column);
 
 /* Flush: emit the next of the D columns still pending after the last frame
- * (feeds no new samples).  Returns EMSPEC_ERR_STATE when nothing is pending. */
+ * (feeds no new samples).  Returns EMSPEC_ERR_STATE when nothing is pending.
+ * A flushed stream is at its end - later frames would still have added to the
+ * columns a flush emits - so feeding it again without emspec_reset() is
+ * EMSPEC_ERR_STATE. */
 int emspec_column_flush(emspec_engine* e, float* out_db, uint8_t* out_rgba,
                         int32_t rows, int64_t* out_column);
 
@@ -252,7 +255,8 @@ int emspec_reset(emspec_engine* e);
  *   (D = emspec_latency_columns), the empty column while a stream's ring primes; out_columns[streams] (optional) the
  *   column index, -1 for the empty column.
  * emspec_columns_flush: every stream that still has pending columns emits its next one (others: the empty column, -1).
- *   EMSPEC_ERR_STATE when no stream has any.  Works for both feeding forms.
+ *   EMSPEC_ERR_STATE when no stream has any.  Works for both feeding forms.  A flushed stream is at its end: feeding the
+ *   session again is EMSPEC_ERR_STATE until that stream is restarted (emspec_reset_stream) or the session reset.
  * emspec_push_samples_multi: per-sample-block form.  samples: `count` new samples of every stream, stream s at
  *   samples + s * stride (stride >= count: a window of a larger [streams][...] array works).  Finished columns of stream s
  *   go to out_db[s][0 .. out_counts[s]) of out_db[streams][max_columns][rows] (and / or out_rgba, same layout + [4]),

@@ -262,3 +262,18 @@ def test_live_session_guards():
         assert ei.value.code == emspec.ERR_INVALID_ARG
         db, _, counts, firsts = e.push_samples_multi(pcm[:, n + hop:n + 12 * hop], n, hop, True)
         assert np.all(counts == 11) and np.all(firsts == 0)
+        # a flush puts every stream with pending columns at its end: feeding again is refused until those streams restart
+        _, _, cols = e.columns_flush()
+        assert np.all(cols == 11)
+        with pytest.raises(emspec.EmspecError) as ei:
+            e.push_samples_multi(pcm[:, :hop], n, hop, True)
+        assert ei.value.code == emspec.ERR_STATE and "flushed" in str(ei.value)
+        for s in range(S):
+            e.reset_stream(s)
+        db, _, counts, firsts = e.push_samples_multi(pcm[:, :n + 4 * hop], n, hop, True)
+        assert np.all(counts == 3) and np.all(firsts == 0)
+        # the same rule for the single-stream calls
+        e.flush()
+        with pytest.raises(emspec.EmspecError) as ei:
+            e.column(pcm[0, :n], hop, True)
+        assert ei.value.code == emspec.ERR_STATE
