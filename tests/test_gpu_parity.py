@@ -927,3 +927,28 @@ def test_short_reciprocal_equals_ieee_division(diag_engine):
     check(bits.view(np.float32))
     # the largest argument the power gate lets through: 64 * 1e36
     check(np.array([64.0 * 1.0e36, np.nextafter(np.float32(64.0e36), np.float32(0))], np.float32))
+
+
+def test_bench_four_rank_rehearsal():
+    """`python bench.py --gpus 4` (the driver's command form at N = 4) with four ranks on this one GPU over gloo: the plain
+    invocation starts its ranks, the split trials run for world 4 (the root lighter, the other three even), the gather collects
+    four shards per chunk, ONE line comes back.  What the driver's N = 4 / 8 runs add is the transport (RCCL, rccl.h:220)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--streams", "16",
+           "--log2-samples", "17", "--chunks", "2", "--backend", "gloo", "--trial-budget-s", "40"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    b = json.loads(lines[0])
+    C = (2 ** 17 - 4096) // 256 + 1
+    counts = b["config"]["streams_per_rank"]
+    assert b["n_gpus"] == 4 and len(counts) == 4 and sum(counts) == 64 and b["config"]["columns_per_step"] == 64 * C and b["value"] > 0
+    trials = [t for t in b["gather"]["split_trials"] if t.get("streams_per_rank")]
+    assert len(trials) >= 2 and all(sum(t["streams_per_rank"]) == 64 and t["streams_per_rank"][0] <= 16 for t in trials)
+    assert all(max(t["streams_per_rank"][1:]) - min(t["streams_per_rank"][1:]) <= 1 for t in trials)
+    assert counts == max(trials, key=lambda t: t["columns_per_s"])["streams_per_rank"]
+
