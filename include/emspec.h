@@ -38,6 +38,7 @@ extern "C" {
 /* 2 (round 4): emspec_config.mode is read (it was a reserved, ignored field in version 1, so a version-1 library would
  * silently run an EXACT-mode request in float32: emspec_create now rejects the mismatch); added emspec_mode,
  * emspec_build_info, emspec_device_status, emspec_comm_set_timeout; emspec_uses_fused answers for EXACT-mode engines too. */
+/* (round 6 added the live multi-stream functions - emspec_columns ... emspec_live_streams - and changed no struct: still 2) */
 #define EMSPEC_ABI_VERSION 2
 
 typedef enum emspec_status {
@@ -245,7 +246,7 @@ int emspec_reset(emspec_engine* e);
  *
  * The first call fixes the session: streams, fft size, hop, reassign and the feeding form (per frame OR per sample block);
  * changing any of them later is EMSPEC_ERR_STATE until emspec_reset().  The session is independent of the single-stream
- * state of emspec_column / emspec_push_samples.  Every stream has its own position: emspec_reset_stream(e, s) restarts
+ * state of emspec_column / emspec_push_samples (which are the one-stream case of the same code, on a session of their own).  Every stream has its own position: emspec_reset_stream(e, s) restarts
  * stream s (its sample position, pending columns and display post-process state) while the others continue.
  * Buffers: any host memory works; when a buffer is page-locked (emspec_host_alloc) the kernel reads / writes it in place
  * (no staging copy on the host thread) - for 64 streams of n = 4096 that is 1 MB of frames per emspec_columns call.
