@@ -468,8 +468,8 @@ def main():
     json_out = os.fdopen(json_fd, "w")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)      # (0.45 s of timed kernels at N = 1: long enough for a utilisation sampler to see)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="batch64", choices=["batch64", "single", "n16384", "n8192", "n1024", "paritydump"],
                     help="paritydump: N=1 only, a step = the per-bin dump of 16 streams x 2^20 samples (the second roofline point of the default line, here on its own so that tools/profile_workload.sh can profile it)")
     ap.add_argument("--streams", type=int, default=0, help="override streams per GPU")
