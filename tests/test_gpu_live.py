@@ -277,3 +277,44 @@ def test_live_session_guards():
         with pytest.raises(emspec.EmspecError) as ei:
             e.column(pcm[0, :n], hop, True)
         assert ei.value.code == emspec.ERR_STATE
+
+
+def test_live_session_of_4000_hops_equals_the_batch_bits():
+    """configs[2]'s 64 streams through the live entry for 2^20 samples each (4,081 hops: every sample ring wraps 63 times, every
+    column ring 85 times), EXACT mode, page-locked blocks: every column's dB bits equal the BATCH call's on the same audio - the
+    size-independent property (live == batch) at a length the CPU oracle does not reach in seconds."""
+    import torch
+    S, n, hop, L = 64, 4096, 256, 1 << 20
+    base = synth.streams(8, L)
+    pcm = np.ascontiguousarray(np.stack([np.roll(base[s % 8], 1013 * s) * np.float32(1.0 - 0.01 * (s % 11)) for s in range(S)]))
+    Cn = emspec.num_columns(L, n, hop)
+    D = emspec.latency_columns(n, hop, True)
+    dev = torch.device("cuda", 0)
+    with emspec.Engine(mode=emspec.MODE_EXACT) as ref:
+        db = torch.empty((S, Cn, 1024), dtype=torch.float32, device=dev)
+        ref.batch_device(torch.from_numpy(pcm).to(dev), n, hop, True, db=db)
+        torch.cuda.synchronize()
+        want = db.cpu().numpy().view(np.uint32)
+        del db
+    blk = emspec.PinnedArray((S, hop), np.float32)
+    out = emspec.PinnedArray((S, 1, 1024), np.float32)
+    bad = seen = 0
+    try:
+        with emspec.Engine(mode=emspec.MODE_EXACT) as e:
+            e.push_samples_multi(pcm[:, :n - hop].copy(), n, hop, True, want_db=False)
+            for j in range(Cn):
+                blk.array[:] = pcm[:, n - hop + j * hop:n + j * hop]
+                _, _, counts, firsts = e.push_samples_multi(blk.array, n, hop, True, db=out.array)
+                if j >= D:
+                    assert np.all(counts == 1) and np.all(firsts == j - D)
+                    bad += int(not np.array_equal(out.array.view(np.uint32)[:, 0], want[:, j - D]))
+                    seen += 1
+            for i in range(D):
+                dbf, _, cols = e.columns_flush()
+                assert np.all(cols == Cn - D + i)
+                bad += int(not np.array_equal(dbf.view(np.uint32), want[:, Cn - D + i]))
+                seen += 1
+    finally:
+        blk.close(); out.close()
+    assert seen == Cn and bad == 0, (seen, bad)
+
