@@ -1054,6 +1054,12 @@ def main():
                 cfgs["node host"] = {"error": repr(ex)}
             line["configs"] = cfgs
             line["config"]["single_stream_columns_per_s"] = one["columns_per_s"]
+            # `value` is the float32 (FAST) mode; the mode that meets north_star's exact-index criterion against a binary64
+            # (JavaScript) evaluation is EXACT: the pair, side by side at the top of the line
+            line["exact_mode"] = {"value": cfgs[xname]["columns_per_s"], "unit": "columns/s", "kernel_ms": cfgs[xname]["kernel_ms"],
+                                  "dtype": "f64", "ratio_to_value": cfgs[xname]["columns_per_s"] / line["value"],
+                                  "note": "the same workload (configs[2]) in EMSPEC_MODE_EXACT: binary64 arithmetic + 64-bit fixed-point "
+                                          "histogram, bit-identical to the binary64 bit model; `value` above is the float32 mode"}
 
             # the per-bin parity dump (power, column, row for every bin: what the exact-index criterion forces
             # to exist in HBM, BASELINE.md "parity mode") timed on 16 of the streams, as a second roofline point
