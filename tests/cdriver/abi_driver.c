@@ -148,10 +148,43 @@ int main(void) {
         CHECK(emspec_columns_flush(x, odb, NULL, R, cols) == EMSPEC_ERR_STATE, "live flush past the end");
         CHECK(emspec_reset(x) == EMSPEC_OK && emspec_live_streams(x) == 0, "reset ends the live session");
         emspec_host_free(blk); emspec_host_free(odb); free(prime);
+        /* the same session from ORDINARY (pageable) memory - the library stages blocks and columns on the host thread - with
+         * blocks of five hops (several columns per call, outputs [S][max_columns][rows]) and dB + RGBA out; then the per-frame
+         * form (emspec_columns) from pageable frames; both against the batch call's bits */
+        {
+            const int B = 5, maxc = 6;
+            float* pb = (float*)malloc(sizeof(float) * S * B * hop);
+            float* pdb = (float*)malloc(sizeof(float) * S * maxc * R);
+            unsigned char* prg = (unsigned char*)malloc((size_t)4 * S * maxc * R);
+            long fed = 0;
+            int next = 0;
+            while (fed + (long)B * hop <= L) {
+                for (int s2 = 0; s2 < S; ++s2) for (int i = 0; i < B * hop; ++i) pb[(size_t)s2 * B * hop + i] = s2 == 0 ? pcm[fed + i] : (s2 == 1 ? 0.5f * pcm[fed + i] : 0.0f);
+                CHECK(emspec_push_columns_multi(x, B * hop, n, hop, 1) <= maxc, "push_columns_multi bound");
+                CHECK(emspec_push_samples_multi(x, pb, S, B * hop, B * hop, n, hop, 1, pdb, prg, R, maxc, counts, firsts) == EMSPEC_OK, emspec_last_error(x));
+                for (int i = 0; i < counts[0]; ++i) {
+                    CHECK(firsts[0] + i == next, "pageable live: column order");
+                    CHECK(memcmp(pdb + (size_t)i * R, xdb + (size_t)next * R, sizeof(float) * R) == 0, "pageable live: stream 0 differs from the batch bits");
+                    CHECK(prg[4 * ((size_t)i * R) + 3] == 255, "pageable live: alpha");
+                    ++next;
+                }
+                fed += (long)B * hop;
+            }
+            CHECK(next >= 10, "pageable live: too few columns");
+            CHECK(emspec_reset(x) == EMSPEC_OK, "reset");
+            float* fr = (float*)malloc(sizeof(float) * S * n);
+            for (int j = 0; j < 12; ++j) {
+                for (int s2 = 0; s2 < S; ++s2) for (int i = 0; i < n; ++i) fr[(size_t)s2 * n + i] = s2 == 0 ? pcm[(long)j * hop + i] : 0.0f;
+                CHECK(emspec_columns(x, fr, S, n, hop, 1, pdb, prg, R, cols) == EMSPEC_OK, emspec_last_error(x));
+                if (j >= D) CHECK(cols[0] == j - D && memcmp(pdb, xdb + (size_t)(j - D) * R, sizeof(float) * R) == 0, "pageable emspec_columns differs from the batch bits");
+            }
+            CHECK(emspec_reset(x) == EMSPEC_OK, "reset");
+            free(pb); free(pdb); free(prg); free(fr);
+        }
     }
     emspec_destroy(x);
     free(xdb); free(xdb2);
     free(pcm); free(db); free(rgba); free(col);
-    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells; live multi-stream session (3 streams, page-locked blocks) == batch bits\n", worst, xworst);
+    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells; live multi-stream session (3 streams, page-locked and pageable blocks, sample- and frame-fed) == batch bits\n", worst, xworst);
     return 0;
 }
