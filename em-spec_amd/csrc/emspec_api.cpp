@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <map>
 #include <new>
 #include <string>
@@ -975,6 +978,159 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     return EMSPEC_OK;
 }
 
+// Host buffers in ORDINARY (pageable) memory.  The runtime serves such copies itself (it pins the pages and streams them: ~45 GB/s
+// one way on this box) but the call returns only when the copy is done, so from one host thread the samples in, the kernels and the
+// columns out run one after the other.  Here the same chunks and staging sets as batch_pipeline, with a second host thread that does
+// nothing but the copies out: in, compute and out overlap as they do from page-locked memory.  Returns kNoThread (not an
+// EMSPEC_ERR_* value) when the thread cannot be started, before anything was done.
+static constexpr int kNoThread = -1000;
+static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
+                                   const emspec_out* out) {
+    int rc;
+    if ((rc = pipe_setup(e))) return rc;
+    const int64_t C = emspec_num_columns(L, n, hop);
+    const int R = e->cfg.rows;
+    const size_t col_cells = (size_t)C * R;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t in_s = (size_t)L * sizeof(float);
+    const size_t db_s = out->db ? col_cells * 4 : 0, rgba_s = out->rgba ? col_cells * 4 : 0, idx_s = out->index ? col_cells : 0;
+    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s);
+    int chunk = (S + 15) / 16;
+    const int fit = (int)(((size_t)1 << 30) / per_stream);
+    chunk = chunk > fit ? fit : chunk;
+    chunk = chunk < 1 ? 1 : chunk;
+    const size_t set_bytes = (size_t)chunk * per_stream;
+    if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, kPipeSets * set_bytes + 1024))) return rc;
+    hipEvent_t* ev_in = e->pipe_ev;
+    hipEvent_t* ev_comp = e->pipe_ev + kPipeSets;
+    const int nchunks = (S + chunk - 1) / chunk;
+    struct Set { float* pcm; float* db; uint8_t* rgba; uint8_t* idx; };
+    auto set_of = [&](int b) {
+        char* base = e->d_stage + (size_t)b * set_bytes;
+        Set q;
+        q.pcm = (float*)base; base += al(in_s) * chunk;
+        q.db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
+        q.rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
+        q.idx = idx_s ? (uint8_t*)base : nullptr;
+        return q;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    int launched = 0, drained = 0;      // chunks whose kernels are enqueued / whose columns are in the caller's memory
+    bool stop = false;
+    hipError_t herr_out = hipSuccess;
+    // A caller that allocates its result per call (np.empty, new Uint8Array) hands over pages that were never touched: the runtime's
+    // copy then takes a page fault per 4 KB on its one thread (1 GB of palette indices: 90 ms of a 114 ms call).  kTouchers threads
+    // write one byte into every page of a chunk's destination before the drainer copies the chunk there (every byte of the outputs
+    // is overwritten by the call anyway); on resident pages that costs nothing measurable.
+    constexpr int kTouchers = 3;
+    int touched[kTouchers] = {};
+    auto touch_all = [&](int t) {
+        auto touch = [&](void* base, size_t bytes) {
+            if (!base || !bytes) return;
+            volatile char* p = reinterpret_cast<volatile char*>(base);
+            const size_t lo = bytes * (size_t)t / kTouchers, hi = bytes * (size_t)(t + 1) / kTouchers;
+            for (size_t a = lo; a < hi; a += 4096) p[a] = 0;
+            if (t == kTouchers - 1) p[bytes - 1] = 0;
+        };
+        for (int f = 0; f < nchunks; ++f) {
+            const int s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+            if (db_s) touch(out->db + (size_t)s0 * col_cells, db_s * sc);
+            if (rgba_s) touch(out->rgba + 4 * (size_t)s0 * col_cells, rgba_s * sc);
+            if (idx_s) touch(out->index + (size_t)s0 * col_cells, idx_s * sc);
+            std::lock_guard<std::mutex> lk(mu);
+            touched[t] = f + 1;
+            cv.notify_all();
+            if (stop) break;
+        }
+    };
+    auto drain_all = [&] {
+        hipError_t r = hipSetDevice(e->device);
+        for (int f = 0; f < nchunks && r == hipSuccess; ++f) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] {
+                    bool ready = launched > f;
+                    for (int t = 0; t < kTouchers; ++t) ready = ready && touched[t] > f;
+                    return ready || stop;
+                });
+                if (launched <= f) break;
+                bool ready = true;
+                for (int t = 0; t < kTouchers; ++t) ready = ready && touched[t] > f;
+                if (!ready) break;
+            }
+            const int b = f % kPipeSets, s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+            const Set q = set_of(b);
+            r = hipStreamWaitEvent(e->stream_out, ev_comp[b], 0);
+            if (r == hipSuccess && db_s) r = hipMemcpyAsync(out->db + (size_t)s0 * col_cells, q.db, db_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess && rgba_s) r = hipMemcpyAsync(out->rgba + 4 * (size_t)s0 * col_cells, q.rgba, rgba_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess && idx_s) r = hipMemcpyAsync(out->index + (size_t)s0 * col_cells, q.idx, idx_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess) r = hipStreamSynchronize(e->stream_out);
+            std::lock_guard<std::mutex> lk(mu);
+            drained = f + 1;
+            cv.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        herr_out = r;
+        stop = true;
+        cv.notify_all();
+    };
+    std::thread drainer, touchers[kTouchers];
+    try {
+        drainer = std::thread(drain_all);
+    } catch (const std::exception&) {   // no thread to be had: the caller falls back to one chunk on its own thread
+        return kNoThread;
+    }
+    for (int t = 0; t < kTouchers; ++t) {
+        try {
+            touchers[t] = std::thread(touch_all, t);
+        } catch (const std::exception&) {   // (its share counts as touched: the runtime takes those faults itself)
+            std::lock_guard<std::mutex> lk(mu);
+            touched[t] = nchunks;
+            cv.notify_all();
+        }
+    }
+    hipError_t herr = hipSuccess;
+    rc = EMSPEC_OK;
+    for (int ci = 0; ci < nchunks && rc == EMSPEC_OK && herr == hipSuccess; ++ci) {
+        const int b = ci % kPipeSets, s0 = ci * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const Set q = set_of(b);
+        if (ci >= kPipeSets) {   // the set is free once chunk ci - kPipeSets has left it
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return drained > ci - kPipeSets || stop; });
+            if (drained <= ci - kPipeSets) break;
+        }
+        herr = hipMemcpyAsync(q.pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, e->stream_in);
+        if (herr == hipSuccess) herr = hipEventRecord(ev_in[b], e->stream_in);
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(e->stream, ev_in[b], 0);
+        if (herr != hipSuccess) break;
+        rc = emspec_batch_device(e, q.pcm, sc, L, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
+        if (rc != EMSPEC_OK) break;
+        herr = hipEventRecord(ev_comp[b], e->stream);
+        if (herr != hipSuccess) break;
+        std::lock_guard<std::mutex> lk(mu);
+        launched = ci + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (launched < nchunks) stop = true;   // an error: the drainer finishes what was launched and leaves
+        cv.notify_all();
+    }
+    drainer.join();
+    for (auto& th : touchers)
+        if (th.joinable()) th.join();
+    const hipError_t s1 = hipStreamSynchronize(e->stream_in), s2 = hipStreamSynchronize(e->stream), s3 = hipStreamSynchronize(e->stream_out);
+    if (rc != EMSPEC_OK) return rc;
+    HIPCHK(e, herr);
+    HIPCHK(e, herr_out);
+    HIPCHK(e, s1);
+    HIPCHK(e, s2);
+    HIPCHK(e, s3);
+    if (read_kernel_error(true) > 0) return fail(e, EMSPEC_ERR_HIP, "a kernel's bounded wait timed out (protocol error): results invalid");
+    return EMSPEC_OK;
+}
+
 bool emspec::host_pinned(const void* p) {
     if (!p) return true;
     hipPointerAttribute_t at;
@@ -992,11 +1148,16 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     if (S < 1 || L < n) return fail(e, EMSPEC_ERR_INVALID_ARG, "need at least one stream of at least fft-size samples");
     HIPCHK(e, hipSetDevice(e->device));
     if (!out->db && !out->rgba && !out->index) return EMSPEC_OK;
-    // The copies reach PCIe speed only from pinned memory: callers that care get it from emspec_host_alloc (pinning the
-    // caller's pageable buffers per call costs more than it saves: measured 49 ms vs 27 ms for 670 MB).  Pageable copies are
-    // staged synchronously by the runtime, so chunking only adds overhead there: one chunk, one stream.
+    // Page-locked buffers (emspec_host_alloc): every copy is asynchronous, one host thread drives the three stages.  Pageable
+    // buffers: the runtime's copies block the calling thread, so a second thread takes the copies out (round 6: 2.15e7 -> 4.3e7
+    // columns/s on the bench shape, the page-locked rate; pinning the caller's buffers per call instead costs more than it
+    // saves: 49 ms vs 27 ms for 670 MB).  One stream cannot be chunked: one copy in, the kernels, one copy out.
     if (S > 1 && host_pinned(pcm) && host_pinned(out->db) && host_pinned(out->rgba) && host_pinned(out->index))
         return batch_pipeline(e, pcm, S, L, n, hop, reassign, out, nullptr);
+    if (S > 1) {
+        rc = batch_pipeline_pageable(e, pcm, S, L, n, hop, reassign, out);
+        if (rc != kNoThread) return rc;
+    }
     const int64_t C = emspec_num_columns(L, n, hop);
     const size_t col_cells = (size_t)C * e->cfg.rows;
     const size_t in_s = (size_t)L * sizeof(float);

@@ -136,7 +136,7 @@ hipError_t launch_postprocess(const float* db, float* out_db, uint8_t* rgba, uin
 // (ncol: the largest number of columns any stream emits - grid (ncol, S), one workgroup per column)
 hipError_t launch_live_flush(bool exact, const LiveSinks& lv, void* cells, int slots, int rows, int D, const DbMap& m,
                              const ExactDbMap& xm, int S, int ncol, hipStream_t st);
-hipError_t launch_live_post(const LiveSinks& lv, const float* raw, int rows, int D, float sm, float agc, float db_top,
+hipError_t launch_live_post(const LiveSinks& lv, const float* raw, int raw_cols, int rows, int D, float sm, float agc, float db_top,
                             const DbMap& dm, float* pstate, int S, hipStream_t st);
 // the gather's wire image (pack.hip.inc)
 int64_t wire_bound_bytes(int64_t columns, int rows);

@@ -107,8 +107,10 @@ int live_post_buffers(emspec_engine* e, LiveState& lv) {
 
 // One launch of the session: the frame kernel (or, flush = true, the flush kernel) and, with the display post-process on,
 // the post kernel behind it.  dst_db / dst_rgba: device-visible destinations laid out [S][out_cols][rows].
+// raw_cols: an upper bound of the output slots any stream uses (out_at + the columns it emits): the stride of the raw block - the
+// caller's max_columns may be far larger than what a call completes.
 int live_launch(emspec_engine* e, LiveState& lv, const float* fresh, int64_t fresh_stride, int mlaunch, bool flush, float* dst_db,
-                uint8_t* dst_rgba, int out_cols, bool empty_col) {
+                uint8_t* dst_rgba, int out_cols, int raw_cols, bool empty_col) {
     Plan* p;
     int rc;
     if ((rc = get_plan(e, lv.n, &p))) return rc;
@@ -136,10 +138,12 @@ int live_launch(emspec_engine* e, LiveState& lv, const float* fresh, int64_t fre
 #endif
     // with the post-process the frame kernel's columns are raw dB on the device, laid out like the destination
     if (post) {
-        if ((size_t)lv.S * out_cols * e->cfg.rows * 4 > lv.raw_bytes &&
-            (rc = grow(e, (void**)&lv.d_raw, &lv.raw_bytes, (size_t)lv.S * out_cols * e->cfg.rows * 4))) return rc;
+        raw_cols = std::max(1, std::min(raw_cols, out_cols));
+        if ((size_t)lv.S * raw_cols * e->cfg.rows * 4 > lv.raw_bytes &&
+            (rc = grow(e, (void**)&lv.d_raw, &lv.raw_bytes, (size_t)lv.S * raw_cols * e->cfg.rows * 4))) return rc;
         ls.out_db = lv.d_raw;
         ls.out_rgba = nullptr;
+        ls.out_cols = raw_cols;
     } else {
         ls.out_db = dst_db;
         ls.out_rgba = reinterpret_cast<uint32_t*>(dst_rgba);
@@ -175,7 +179,8 @@ int live_launch(emspec_engine* e, LiveState& lv, const float* fresh, int64_t fre
     if (post) {
         ls.out_db = dst_db;
         ls.out_rgba = reinterpret_cast<uint32_t*>(dst_rgba);
-        HIPCHK(e, launch_live_post(ls, lv.d_raw, e->cfg.rows, lv.D, e->smoothing, e->agc, e->cfg.db_top, m, lv.d_pstate, lv.S, e->stream));
+        ls.out_cols = out_cols;
+        HIPCHK(e, launch_live_post(ls, lv.d_raw, raw_cols, e->cfg.rows, lv.D, e->smoothing, e->agc, e->cfg.db_top, m, lv.d_pstate, lv.S, e->stream));
     }
     return EMSPEC_OK;
 }
@@ -227,7 +232,7 @@ int columns_impl(emspec_engine* e, LiveState& lv, const float* frames, int32_t s
     if (stage_rgba) drgba = lv.h_orgba;
     LiveStream* desc = reinterpret_cast<LiveStream*>(lv.h_desc);
     for (int s = 0; s < S; ++s) desc[s] = LiveStream{lv.fed[s], lv.fed[s] * (long long)hop, 1, 0, 0, 0};
-    if ((rc = live_launch(e, lv, src, n, 1, false, ddb, drgba, 1, true))) return live_abandon(e, lv, rc);
+    if ((rc = live_launch(e, lv, src, n, 1, false, ddb, drgba, 1, 1, true))) return live_abandon(e, lv, rc);
     if (hipStreamSynchronize(e->stream) != hipSuccess) return live_abandon(e, lv, fail(e, EMSPEC_ERR_HIP, "hipStreamSynchronize failed"));
     if (stage_db) std::memcpy(out_db, lv.h_odb, (size_t)S * R * 4);
     if (stage_rgba) std::memcpy(out_rgba, lv.h_orgba, (size_t)S * R * 4);
@@ -261,7 +266,7 @@ int flush_impl(emspec_engine* e, LiveState& lv, float* out_db, uint8_t* out_rgba
         // (a stream with nothing pending emits the empty column: "column -1")
         desc[s] = LiveStream{has ? lv.emitted[s] + lv.D : (long long)lv.D - 1, 0, 0, 0, 0, 1};
     }
-    if ((rc = live_launch(e, lv, nullptr, 0, 0, true, ddb, drgba, 1, true))) return live_abandon(e, lv, rc);
+    if ((rc = live_launch(e, lv, nullptr, 0, 0, true, ddb, drgba, 1, 1, true))) return live_abandon(e, lv, rc);
     if (hipStreamSynchronize(e->stream) != hipSuccess) return live_abandon(e, lv, fail(e, EMSPEC_ERR_HIP, "hipStreamSynchronize failed"));
     if (stage_db) std::memcpy(out_db, lv.h_odb, (size_t)S * R * 4);
     if (stage_rgba) std::memcpy(out_rgba, lv.h_orgba, (size_t)S * R * 4);
@@ -344,7 +349,8 @@ int push_impl(emspec_engine* e, LiveState& lv, const float* samples, int32_t str
             desc[s] = LiveStream{lv.fed[s], lv.newbase[s], M[s], lv.pend[s], direct ? (int)produced[s] : 0, 0};
             if (nc[s] > 0 && first[s] < 0) first[s] = c0;
         }
-        if ((rc = live_launch(e, lv, lv.h_fresh, lv.cap, mx, false, ddb, drgba, direct ? (int)max_columns : lv.mmax, false)))
+        if ((rc = live_launch(e, lv, lv.h_fresh, lv.cap, mx, false, ddb, drgba, direct ? (int)max_columns : lv.mmax,
+                              direct ? (int)std::min<int64_t>(std::max<int64_t>(expect, 1), 0x7fffffff) : lv.mmax, false)))
             return live_abandon(e, lv, rc);
         inflight = true;
         if (!direct && (out_db || out_rgba)) {

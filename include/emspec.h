@@ -284,16 +284,20 @@ int32_t emspec_live_streams(const emspec_engine* e);
  * When every buffer is page-locked (emspec_host_alloc) the call runs a three-stage pipeline over ~16 chunks of streams -
  * host->device copies, kernels, device->host copies on three HIP streams of the engine - in either arithmetic mode and with
  * the display post-process; what bounds it is PCIe (uint8 index out: ~45 GB/s each way at once on a Gen5 x16 link).
- * Pageable buffers take one stream, chunk after chunk (staging bounded at 4 GiB).  Serves: the renderer-side batched
- * computeColumns of the N-API addon (em-spec_amd/js/index.js).
+ * Ordinary (pageable) buffers run the same pipeline: the runtime's copies block the calling thread, so the library starts a
+ * second host thread for the copies out (and three that touch the destination's pages ahead of it - a result array allocated
+ * per call has none resident), all joined before the call returns: the page-locked rate when the pages are resident (4.3e7
+ * columns/s on the bench shape), a third of it into a fresh array.  One stream (S = 1) cannot be chunked: one copy in, the
+ * kernels, one copy out.  Serves: the renderer-side batched computeColumns of the N-API addon (em-spec_amd/js/index.js).
  */
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
                  int32_t n, int32_t hop, int32_t reassign, const emspec_out* out);
 
 /*
- * Page-locked host memory for the buffers of emspec_batch / emspec_column: copies from and to it
- * run at full PCIe speed (pageable memory is staged by the runtime at roughly half that).  Optional:
- * any host memory works.  Needs no engine; free with emspec_host_free.
+ * Page-locked host memory for the buffers of emspec_batch / emspec_column / the live calls: copies from and to it
+ * are asynchronous and need no extra host thread, and the streaming kernels read / write it in place (pageable
+ * memory costs the streaming calls a staging copy each way).  Optional: any host memory works.  Needs no engine;
+ * free with emspec_host_free.
  */
 int emspec_host_alloc(size_t bytes, void** out);
 void emspec_host_free(void* p);

@@ -1,6 +1,6 @@
 """-m gpu: the host-buffer entry points (emspec_batch / emspec_batch_packed) - the three-stage pipeline over chunks of
-streams (H2D | kernels | D2H on three HIP streams, three staging sets) must return exactly what the device-resident call
-returns, in both arithmetic modes and with the display post-process, and the packed form's images must expand (on the
+streams (H2D | kernels | D2H on three HIP streams, three staging sets; from pageable memory with a second host thread for the
+copies out) must return exactly what the device-resident call returns, in both arithmetic modes and with the display post-process, and the packed form's images must expand (on the
 host, emspec_wire_unpack_host) to the same palette indices."""
 import os
 import sys
@@ -48,6 +48,30 @@ def _batch_pinned(e, pcm, n, hop, want=("db", "index")):
             pdb.close()
         if pix:
             pix.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+@pytest.mark.parametrize("S", [2, 23])
+def test_pageable_batch_equals_pinned_batch(mode, S):
+    """Ordinary numpy arrays (pageable): the pipeline's copies out run on a second host thread (round 6).  23 streams = 12 chunks
+    through three staging sets, 2 streams = fewer chunks than sets; dB, RGBA and palette index out at once; twice.  EXACT: bytes equal to the page-locked call's; FAST: equal but for its +-1 cells."""
+    n, hop = 4096, 256
+    L = n + hop * 149 + 5
+    pcm = synth.streams(S, L)
+    with emspec.Engine(mode=emspec.MODE_EXACT if mode == "exact" else emspec.MODE_FAST) as e:
+        ref = _batch_pinned(e, pcm, n, hop)
+        lut = emspec.make_colormap(0.7)
+        e.set_colormap(lut)
+        for _ in range(2):
+            got = e.batch(pcm, n, hop, True, want=("db", "rgba", "index"))
+            if mode == "exact":
+                assert np.array_equal(got["index"], ref["index"])
+                assert np.array_equal(got["db"].view(np.uint32), ref["db"].view(np.uint32))
+            else:
+                d = np.abs(got["index"].astype(int) - ref["index"].astype(int))
+                assert d.max() <= 1 and np.mean(d != 0) < 1e-4
+                assert np.max(np.abs(got["db"] - ref["db"])) < 1e-3
+            assert np.array_equal(got["rgba"], np.asarray(lut).reshape(256, 4)[got["index"]])
 
 
 @pytest.mark.parametrize("mode", ["fast", "exact"])

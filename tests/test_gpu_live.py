@@ -229,6 +229,35 @@ def test_live_display_postprocess_matches_sequential_restatement(exact):
     assert np.max(np.abs(got - want)) < 2e-3, float(np.max(np.abs(got - want)))
 
 
+def test_live_display_postprocess_into_an_oversized_pinned_block():
+    """The post-process keeps the raw columns in a device block of its own stride (what the call completes, not the caller's
+    max_columns): page-locked outputs of 40 columns per stream, three completed per call, written in place."""
+    S, n, hop, frames = 3, 2048, 256, 40
+    pcm = synth.streams(S, n + hop * (frames - 1))
+    cfg = O.make_cfg(n, hop, True)
+    odb, _ = _oracle(n, hop, True, pcm, False, want=("db",))
+    want = O.postprocess(odb, 0.5, 0.7, cfg)[0]
+    D = emspec.latency_columns(n, hop, True)
+    pin = emspec.PinnedArray((S, 40, 1024), np.float32)
+    pin_rgba = emspec.PinnedArray((S, 40, 1024, 4), np.uint8)
+    got = np.empty_like(odb)
+    with emspec.Engine() as e:
+        e.set_display(0.5, 0.7)
+        nxt = 0
+        for a in range(0, pcm.shape[1], 3 * hop):
+            cnt = min(3 * hop, pcm.shape[1] - a)
+            pin.array[...] = -1.0
+            db, rgba, counts, firsts = e.push_samples_multi(pcm, n, hop, True, want_rgba=True, db=pin.array, rgba=pin_rgba.array,
+                                                            count=cnt, offset=a)
+            k = int(counts[0])
+            assert np.all(counts == k) and k <= 3
+            assert np.all(pin.array[:, k:] == -1.0)          # nothing beyond the completed columns is touched
+            got[:, nxt:nxt + k] = pin.array[:, :k]
+            nxt += k
+        assert nxt == frames - D
+    assert np.max(np.abs(got[:, :nxt] - want[:, :nxt])) < 2e-3
+
+
 def test_live_session_guards():
     S, n, hop = 3, 1024, 256
     pcm = synth.streams(S, n + hop * 20)
