@@ -407,6 +407,12 @@ def node_host_configs(pcm_dev, L, n, hop, runs=5):
         base = f"node host (pinned, {d['node']}): {mname}{S} streams, FFT {n}, hop {hop}, reassignment ON"
         out[f"{base}, uint8 palette index out (computeColumnsAsync)"] = {
             "columns_per_s": k["index_out"]["columns_per_s"], "ms": k["index_out"]["ms"], "runs_ms": k["index_out"]["runs"]}
+        if "index_out_plain_arrays" in k:
+            pk = k["index_out_plain_arrays"]
+            out[f"node host (ordinary typed arrays, {d['node']}): {mname}{S} streams, FFT {n}, hop {hop}, reassignment ON, "
+                f"uint8 palette index out (computeColumnsAsync)"] = {
+                "columns_per_s": pk["columns_per_s"], "ms": pk["ms"], "runs_ms": pk["runs"],
+                "sampled_cells_equal_to_pinned": pk["sampled_cells_equal_to_pinned"]}
         out[f"{base}, packed wire images out (computeColumnsPackedAsync)"] = {
             "columns_per_s": k["packed"]["columns_per_s"], "ms": k["packed"]["ms"], "runs_ms": k["packed"]["runs"],
             "wire_bytes_per_column": k["packed"]["wire_bytes_per_column"]}

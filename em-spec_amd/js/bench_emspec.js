@@ -57,6 +57,16 @@ async function main() {
     let ts = [];
     for (let r = 0; r < runs; r++) { const t0 = now(); await eng.computeColumnsAsync(pcm, S, L, n, hop, true, { index }); ts.push(now() - t0); }
     out[key].index_out = { columns_per_s: S * C / median(ts), ms: median(ts) * 1e3, runs: ts.map((t) => +(t * 1e3).toFixed(2)) };
+    // the same call from ORDINARY typed arrays (what a caller that knows nothing of allocPinned writes), reused across calls
+    if (!exact) {
+      const plainPcm = new Float32Array(pcm), plainIndex = new Uint8Array(S * C * R);
+      await eng.computeColumnsAsync(plainPcm, S, L, n, hop, true, { index: plainIndex });
+      ts = [];
+      for (let r = 0; r < runs; r++) { const t0 = now(); await eng.computeColumnsAsync(plainPcm, S, L, n, hop, true, { index: plainIndex }); ts.push(now() - t0); }
+      let same = true;
+      for (let i = 0; i < plainIndex.length && same; i += 4099) same = Math.abs(plainIndex[i] - index[i]) <= 1;
+      out[key].index_out_plain_arrays = { columns_per_s: S * C / median(ts), ms: median(ts) * 1e3, runs: ts.map((t) => +(t * 1e3).toFixed(2)), sampled_cells_equal_to_pinned: same };
+    }
     await eng.computeColumnsPackedAsync(pcm, S, L, n, hop, true, wire, offs);
     ts = [];
     for (let r = 0; r < runs; r++) { const t0 = now(); await eng.computeColumnsPackedAsync(pcm, S, L, n, hop, true, wire, offs); ts.push(now() - t0); }
