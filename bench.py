@@ -305,6 +305,23 @@ def host_buffer_configs(eng, pcm_dev, L, n, hop, R):
             "roofline": {"bound": "pcie", "achieved": gbs, "peak": min(h2d, d2h), "unit": "GB/s", "frac": gbs / min(h2d, d2h),
                          "note": "as the pinned entry; ordinary numpy arrays with resident pages, the copies out on the library's second host thread"}}
         del pg_in, pg_idx
+        # configs[1] through the host entry: ONE long stream (2^25 samples = 11.7 min of audio), pipelined by runs of its columns
+        L1 = 1 << 25
+        C1 = emspec.num_columns(L1, n, hop)
+        p1, x1 = emspec.PinnedArray((1, L1), np.float32), emspec.PinnedArray((1, C1, R), np.uint8)
+        try:
+            reps = -(-L1 // L)
+            p1.array[0, :] = np.tile(pin.array[0], reps)[:L1]
+            o1 = emspec.Out(None, None, C_.c_void_p(x1.array.ctypes.data))
+            dt = timed(lambda: eng._chk(lib.emspec_batch(eng._h, C_.c_void_p(p1.array.ctypes.data), 1, L1, n, hop, 1, C_.byref(o1))))
+            gbs = p1.array.nbytes / dt / 1e9
+            out[f"host buffers (pinned): configs[1] shape - 1 stream of 2^25 samples, FFT {n}, hop {hop}, reassignment ON, uint8 palette index out (emspec_batch)"] = {
+                "columns_per_s": C1 / dt, "ms": dt * 1e3,
+                "roofline": {"bound": "pcie", "achieved": gbs, "peak": min(h2d, d2h), "unit": "GB/s", "frac": gbs / min(h2d, d2h),
+                             "note": "one stream cannot be chunked by streams: the pipeline's units are runs of >= 16,384 of its columns (+ D halo frames either side)"}}
+        finally:
+            p1.close()
+            x1.close()
         # (last: the test makes two more HIP streams, and which copy engine a stream's transfers use follows from creation order)
         duplex = duplex_rate()
         rf = out[idx_name]["roofline"]

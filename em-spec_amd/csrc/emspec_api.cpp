@@ -11,6 +11,7 @@
 #include "../../include/emspec_debug.h"
 #pragma GCC visibility pop
 #endif
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -854,6 +855,51 @@ static int pipe_setup(emspec_engine* e) {
     return EMSPEC_OK;
 }
 
+// One unit of the host pipelines: `sc` whole streams from stream s0 on - or, when the batch has fewer streams than the pipeline
+// needs units (BASELINE configs[1] is ONE stream), a run of columns [c0, c0 + cn) of one stream, computed as a batch of its own
+// from the frames that reach those columns: D more on either side (a bin moves at most D columns), whose own columns - `skip` in
+// front, the rest behind - are computed and left on the device.  Every frame that adds to a kept column is in the run and no
+// other frame can reach it, so the kept columns are the whole batch's (EXACT mode: the same bytes; float32: the same sums in
+// another order, as between any two launches).
+struct PipeItem { int s0, sc; int64_t c0, cn, first_sample, samples, skip, cols; };
+static constexpr int kNoThread = -1000, kNoPipeline = -1001;   // pipeline not taken (not EMSPEC_ERR_* values): no helper thread / one unit only
+
+static std::vector<PipeItem> pipe_items(int S, int64_t L, int64_t C, int n, int hop, int D, size_t per_stream_bytes, bool by_time) {
+    std::vector<PipeItem> items;
+    int target = 16;
+#ifdef EMSPEC_DIAG
+    if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) target = v; }   // A/B aid
+#endif
+    // runs of columns: when there are fewer than `target` streams; at least 16,384 columns per run - a unit costs ~0.2 ms of
+    // launches and cross-stream event waits (EXACT: 0.4) whatever its size, and 16 MB each way over PCIe take 0.35 ms (measured
+    // with 2,048-column runs: one stream of 2^22 samples 1.49 ms instead of 0.84 in one piece)
+    const int64_t pieces = by_time && S < target ? std::min<int64_t>((target + S - 1) / S, C / 16384) : 1;
+    if (pieces > 1) {
+        for (int s = 0; s < S; ++s)
+            for (int64_t t = 0; t < pieces; ++t) {
+                PipeItem it;
+                it.s0 = s; it.sc = 1;
+                it.c0 = C * t / pieces;
+                it.cn = C * (t + 1) / pieces - it.c0;
+                const int64_t f0 = std::max<int64_t>(it.c0 - D, 0), f1 = std::min<int64_t>(it.c0 + it.cn + D, C);   // frames [f0, f1)
+                it.first_sample = f0 * hop;
+                it.samples = (f1 - f0 - 1) * hop + n;
+                it.skip = it.c0 - f0;
+                it.cols = f1 - f0;
+                items.push_back(it);
+            }
+        return items;
+    }
+    // chunks of streams: about `target` per batch (pipeline fill and drain stay small beside the steady state), bounded by
+    // 1 GiB of staging per set; a chunk of a few streams still fills the chip (segments are cut per launch)
+    int chunk = (S + target - 1) / target;
+    const int fit = (int)(((size_t)1 << 30) / per_stream_bytes);
+    chunk = chunk > fit ? fit : chunk;
+    chunk = chunk < 1 ? 1 : chunk;
+    for (int s0 = 0; s0 < S; s0 += chunk) items.push_back(PipeItem{s0, std::min(chunk, S - s0), 0, C, 0, L, 0, C});
+    return items;
+}
+
 static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
                           const emspec_out* out, const PackedOut* pk) {
     int rc;
@@ -863,21 +909,24 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     const size_t col_cells = (size_t)C * R;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t in_s = (size_t)L * sizeof(float);
-    const size_t db_s = (out && out->db) ? col_cells * 4 : 0, rgba_s = (out && out->rgba) ? col_cells * 4 : 0;
-    const size_t idx_s = ((out && out->index) || pk) ? col_cells : 0;
+    const bool want_db = out && out->db, want_rgba = out && out->rgba, want_idx = (out && out->index) || pk;
     const size_t wire_s = pk ? (size_t)wire_bound_bytes(C, R) : 0;
-    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s) + al(wire_s);
-    // chunks: about sixteen per batch (pipeline fill and drain stay small beside the steady state), bounded by 1 GiB of
-    // staging per set; a chunk of a few streams still fills the chip (segments are cut per launch)
-    int target = 16;
-#ifdef EMSPEC_DIAG
-    if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) target = v; }   // A/B aid
-#endif
-    int chunk = (S + target - 1) / target;
-    const int fit = (int)(((size_t)1 << 30) / per_stream);
-    chunk = chunk > fit ? fit : chunk;
-    chunk = chunk < 1 ? 1 : chunk;
-    const size_t set_bytes = (size_t)chunk * per_stream;
+    const size_t per_stream = al(in_s) + al(want_db ? col_cells * 4 : 0) + al(want_rgba ? col_cells * 4 : 0) + al(want_idx ? col_cells : 0) + al(wire_s);
+    // (an image is one stream's whole run of columns, and the display post-process walks a stream in time order: whole streams there)
+    const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
+    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !pk && !post);
+    const int nchunks = (int)items.size();
+    if (nchunks < 2 && !pk) return kNoPipeline;   // one unit: nothing to overlap (the caller's plain path)
+    // the staging set: every array at the size its largest unit needs
+    size_t cap_in = 0, cap_cells = 0;
+    int chunk = 1;
+    for (const PipeItem& it : items) {
+        cap_in = std::max(cap_in, al((size_t)it.samples * 4 * it.sc));
+        cap_cells = std::max(cap_cells, (size_t)it.cols * R * it.sc);
+        chunk = std::max(chunk, it.sc);
+    }
+    const size_t cap_db = want_db ? al(cap_cells * 4) : 0, cap_rgba = want_rgba ? al(cap_cells * 4) : 0, cap_idx = want_idx ? al(cap_cells) : 0;
+    const size_t set_bytes = cap_in + cap_db + cap_rgba + cap_idx + al(wire_s) * chunk;
     if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, kPipeSets * set_bytes + 1024))) return rc;
     if (pk) {
         if ((rc = grow(e, (void**)&e->d_packscratch, &e->packscratch_bytes, wire_scratch_bytes(C)))) return rc;
@@ -893,30 +942,31 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     hipEvent_t* ev_in = e->pipe_ev;
     hipEvent_t* ev_comp = e->pipe_ev + kPipeSets;
     hipEvent_t* ev_out = e->pipe_ev + 2 * kPipeSets;
-    const int nchunks = (S + chunk - 1) / chunk;
     struct Set { float* pcm; float* db; uint8_t* rgba; uint8_t* idx; uint8_t* wire; };
     auto set_of = [&](int b) {
         char* base = e->d_stage + (size_t)b * set_bytes;
         Set q;
-        q.pcm = (float*)base; base += al(in_s) * chunk;
-        q.db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
-        q.rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
-        q.idx = idx_s ? (uint8_t*)base : nullptr; base += al(idx_s) * chunk;
+        q.pcm = (float*)base; base += cap_in;
+        q.db = cap_db ? (float*)base : nullptr; base += cap_db;
+        q.rgba = cap_rgba ? (uint8_t*)base : nullptr; base += cap_rgba;
+        q.idx = cap_idx ? (uint8_t*)base : nullptr; base += cap_idx;
         q.wire = wire_s ? (uint8_t*)base : nullptr;
         return q;
     };
     hipError_t herr = hipSuccess;
     rc = EMSPEC_OK;
     std::string why;
-    // the D2H stage of chunk f (its kernels are enqueued; with pk: wait for them, then the images' sizes are known)
+    // the D2H stage of unit f (its kernels are enqueued; with pk: wait for them, then the images' sizes are known)
     auto drain = [&](int f) {
-        const int b = f % kPipeSets, s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const PipeItem& it = items[f];
+        const int b = f % kPipeSets, s0 = it.s0, sc = it.sc;
         const Set q = set_of(b);
         if (!pk) {
+            const size_t from = (size_t)it.skip * R, to = ((size_t)s0 * C + (size_t)it.c0) * R, cells = (size_t)it.cn * R * sc;
             herr = hipStreamWaitEvent(e->stream_out, ev_comp[b], 0);
-            if (herr == hipSuccess && db_s) herr = hipMemcpyAsync(out->db + (size_t)s0 * col_cells, q.db, db_s * sc, hipMemcpyDeviceToHost, e->stream_out);
-            if (herr == hipSuccess && rgba_s) herr = hipMemcpyAsync(out->rgba + 4 * (size_t)s0 * col_cells, q.rgba, rgba_s * sc, hipMemcpyDeviceToHost, e->stream_out);
-            if (herr == hipSuccess && idx_s) herr = hipMemcpyAsync(out->index + (size_t)s0 * col_cells, q.idx, idx_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (herr == hipSuccess && want_db) herr = hipMemcpyAsync(out->db + to, q.db + from, cells * 4, hipMemcpyDeviceToHost, e->stream_out);
+            if (herr == hipSuccess && want_rgba) herr = hipMemcpyAsync(out->rgba + 4 * to, q.rgba + 4 * from, cells * 4, hipMemcpyDeviceToHost, e->stream_out);
+            if (herr == hipSuccess && out->index) herr = hipMemcpyAsync(out->index + to, q.idx + from, cells, hipMemcpyDeviceToHost, e->stream_out);
         } else {
             herr = hipEventSynchronize(ev_comp[b]);
             for (int i = 0; i < sc && herr == hipSuccess && rc == EMSPEC_OK; ++i) {
@@ -943,17 +993,19 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     };
     int drained = 0;
     for (int ci = 0; ci < nchunks && rc == EMSPEC_OK && herr == hipSuccess; ++ci) {
-        const int b = ci % kPipeSets, s0 = ci * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const PipeItem& it = items[ci];
+        const int b = ci % kPipeSets, sc = it.sc;
         const Set q = set_of(b);
-        // stage 1: samples in (the set's input is free once the kernels of chunk ci - kPipeSets are done)
+        // stage 1: samples in (the set's input is free once the kernels of unit ci - kPipeSets are done)
         if (ci >= kPipeSets) herr = hipStreamWaitEvent(e->stream_in, ev_comp[b], 0);
-        if (herr == hipSuccess) herr = hipMemcpyAsync(q.pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, e->stream_in);
+        if (herr == hipSuccess)
+            herr = hipMemcpyAsync(q.pcm, pcm + (size_t)it.s0 * L + (size_t)it.first_sample, (size_t)it.samples * 4 * sc, hipMemcpyHostToDevice, e->stream_in);
         if (herr == hipSuccess) herr = hipEventRecord(ev_in[b], e->stream_in);
-        // stage 2: kernels (the set's outputs are free once chunk ci - kPipeSets has been copied out)
+        // stage 2: kernels (the set's outputs are free once unit ci - kPipeSets has been copied out)
         if (herr == hipSuccess) herr = hipStreamWaitEvent(e->stream, ev_in[b], 0);
         if (herr == hipSuccess && ci >= kPipeSets) herr = hipStreamWaitEvent(e->stream, ev_out[b], 0);
         if (herr != hipSuccess) break;
-        rc = emspec_batch_device(e, q.pcm, sc, L, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
+        rc = emspec_batch_device(e, q.pcm, sc, it.samples, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
         if (rc != EMSPEC_OK) break;
         if (pk) {
             for (int i = 0; i < sc && herr == hipSuccess; ++i) {
@@ -963,7 +1015,7 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
             }
         }
         if (herr == hipSuccess) herr = hipEventRecord(ev_comp[b], e->stream);
-        // stage 3, kPipeLag chunks behind when the host has to read the sizes first
+        // stage 3, kPipeLag units behind when the host has to read the sizes first
         const int lag = pk ? kPipeLag : 0;
         while (herr == hipSuccess && rc == EMSPEC_OK && drained <= ci - lag) drain(drained++);
     }
@@ -983,7 +1035,6 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
 // columns out run one after the other.  Here the same chunks and staging sets as batch_pipeline, with a second host thread that does
 // nothing but the copies out: in, compute and out overlap as they do from page-locked memory.  Returns kNoThread (not an
 // EMSPEC_ERR_* value) when the thread cannot be started, before anything was done.
-static constexpr int kNoThread = -1000;
 static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32_t n, int32_t hop, int32_t reassign,
                                    const emspec_out* out) {
     int rc;
@@ -993,26 +1044,37 @@ static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S
     const size_t col_cells = (size_t)C * R;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t in_s = (size_t)L * sizeof(float);
-    const size_t db_s = out->db ? col_cells * 4 : 0, rgba_s = out->rgba ? col_cells * 4 : 0, idx_s = out->index ? col_cells : 0;
-    const size_t per_stream = al(in_s) + al(db_s) + al(rgba_s) + al(idx_s);
-    int chunk = (S + 15) / 16;
-    const int fit = (int)(((size_t)1 << 30) / per_stream);
-    chunk = chunk > fit ? fit : chunk;
-    chunk = chunk < 1 ? 1 : chunk;
-    const size_t set_bytes = (size_t)chunk * per_stream;
+    const bool want_db = out->db != nullptr, want_rgba = out->rgba != nullptr, want_idx = out->index != nullptr;
+    const size_t per_stream = al(in_s) + al(want_db ? col_cells * 4 : 0) + al(want_rgba ? col_cells * 4 : 0) + al(want_idx ? col_cells : 0);
+    const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
+    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !post);
+    const int nchunks = (int)items.size();
+    if (nchunks < 2) return kNoPipeline;   // one unit: nothing to overlap
+    size_t cap_in = 0, cap_cells = 0;
+    for (const PipeItem& it : items) {
+        cap_in = std::max(cap_in, al((size_t)it.samples * 4 * it.sc));
+        cap_cells = std::max(cap_cells, (size_t)it.cols * R * it.sc);
+    }
+    const size_t cap_db = want_db ? al(cap_cells * 4) : 0, cap_rgba = want_rgba ? al(cap_cells * 4) : 0, cap_idx = want_idx ? al(cap_cells) : 0;
+    const size_t set_bytes = cap_in + cap_db + cap_rgba + cap_idx;
     if ((rc = grow(e, (void**)&e->d_stage, &e->stage_bytes, kPipeSets * set_bytes + 1024))) return rc;
     hipEvent_t* ev_in = e->pipe_ev;
     hipEvent_t* ev_comp = e->pipe_ev + kPipeSets;
-    const int nchunks = (S + chunk - 1) / chunk;
     struct Set { float* pcm; float* db; uint8_t* rgba; uint8_t* idx; };
     auto set_of = [&](int b) {
         char* base = e->d_stage + (size_t)b * set_bytes;
         Set q;
-        q.pcm = (float*)base; base += al(in_s) * chunk;
-        q.db = db_s ? (float*)base : nullptr; base += al(db_s) * chunk;
-        q.rgba = rgba_s ? (uint8_t*)base : nullptr; base += al(rgba_s) * chunk;
-        q.idx = idx_s ? (uint8_t*)base : nullptr;
+        q.pcm = (float*)base; base += cap_in;
+        q.db = cap_db ? (float*)base : nullptr; base += cap_db;
+        q.rgba = cap_rgba ? (uint8_t*)base : nullptr; base += cap_rgba;
+        q.idx = cap_idx ? (uint8_t*)base : nullptr;
         return q;
+    };
+    // where unit f's kept columns go in the caller's arrays / come from in the set: cell offsets and count
+    auto span_of = [&](const PipeItem& it, size_t& from, size_t& to, size_t& cells) {
+        from = (size_t)it.skip * R;
+        to = ((size_t)it.s0 * C + (size_t)it.c0) * R;
+        cells = (size_t)it.cn * R * it.sc;
     };
     std::mutex mu;
     std::condition_variable cv;
@@ -1034,10 +1096,11 @@ static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S
             if (t == kTouchers - 1) p[bytes - 1] = 0;
         };
         for (int f = 0; f < nchunks; ++f) {
-            const int s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
-            if (db_s) touch(out->db + (size_t)s0 * col_cells, db_s * sc);
-            if (rgba_s) touch(out->rgba + 4 * (size_t)s0 * col_cells, rgba_s * sc);
-            if (idx_s) touch(out->index + (size_t)s0 * col_cells, idx_s * sc);
+            size_t from, to, cells;
+            span_of(items[f], from, to, cells);
+            if (want_db) touch(out->db + to, cells * 4);
+            if (want_rgba) touch(out->rgba + 4 * to, cells * 4);
+            if (want_idx) touch(out->index + to, cells);
             std::lock_guard<std::mutex> lk(mu);
             touched[t] = f + 1;
             cv.notify_all();
@@ -1059,12 +1122,14 @@ static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S
                 for (int t = 0; t < kTouchers; ++t) ready = ready && touched[t] > f;
                 if (!ready) break;
             }
-            const int b = f % kPipeSets, s0 = f * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+            const int b = f % kPipeSets;
             const Set q = set_of(b);
+            size_t from, to, cells;
+            span_of(items[f], from, to, cells);
             r = hipStreamWaitEvent(e->stream_out, ev_comp[b], 0);
-            if (r == hipSuccess && db_s) r = hipMemcpyAsync(out->db + (size_t)s0 * col_cells, q.db, db_s * sc, hipMemcpyDeviceToHost, e->stream_out);
-            if (r == hipSuccess && rgba_s) r = hipMemcpyAsync(out->rgba + 4 * (size_t)s0 * col_cells, q.rgba, rgba_s * sc, hipMemcpyDeviceToHost, e->stream_out);
-            if (r == hipSuccess && idx_s) r = hipMemcpyAsync(out->index + (size_t)s0 * col_cells, q.idx, idx_s * sc, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess && want_db) r = hipMemcpyAsync(out->db + to, q.db + from, cells * 4, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess && want_rgba) r = hipMemcpyAsync(out->rgba + 4 * to, q.rgba + 4 * from, cells * 4, hipMemcpyDeviceToHost, e->stream_out);
+            if (r == hipSuccess && want_idx) r = hipMemcpyAsync(out->index + to, q.idx + from, cells, hipMemcpyDeviceToHost, e->stream_out);
             if (r == hipSuccess) r = hipStreamSynchronize(e->stream_out);
             std::lock_guard<std::mutex> lk(mu);
             drained = f + 1;
@@ -1093,18 +1158,19 @@ static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S
     hipError_t herr = hipSuccess;
     rc = EMSPEC_OK;
     for (int ci = 0; ci < nchunks && rc == EMSPEC_OK && herr == hipSuccess; ++ci) {
-        const int b = ci % kPipeSets, s0 = ci * chunk, sc = (S - s0 < chunk) ? S - s0 : chunk;
+        const PipeItem& it = items[ci];
+        const int b = ci % kPipeSets, sc = it.sc;
         const Set q = set_of(b);
-        if (ci >= kPipeSets) {   // the set is free once chunk ci - kPipeSets has left it
+        if (ci >= kPipeSets) {   // the set is free once unit ci - kPipeSets has left it
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return drained > ci - kPipeSets || stop; });
             if (drained <= ci - kPipeSets) break;
         }
-        herr = hipMemcpyAsync(q.pcm, pcm + (size_t)s0 * L, in_s * sc, hipMemcpyHostToDevice, e->stream_in);
+        herr = hipMemcpyAsync(q.pcm, pcm + (size_t)it.s0 * L + (size_t)it.first_sample, (size_t)it.samples * 4 * sc, hipMemcpyHostToDevice, e->stream_in);
         if (herr == hipSuccess) herr = hipEventRecord(ev_in[b], e->stream_in);
         if (herr == hipSuccess) herr = hipStreamWaitEvent(e->stream, ev_in[b], 0);
         if (herr != hipSuccess) break;
-        rc = emspec_batch_device(e, q.pcm, sc, L, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
+        rc = emspec_batch_device(e, q.pcm, sc, it.samples, n, hop, reassign, q.db, q.rgba, q.idx, e->stream);
         if (rc != EMSPEC_OK) break;
         herr = hipEventRecord(ev_comp[b], e->stream);
         if (herr != hipSuccess) break;
@@ -1151,13 +1217,13 @@ int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L, int32
     // Page-locked buffers (emspec_host_alloc): every copy is asynchronous, one host thread drives the three stages.  Pageable
     // buffers: the runtime's copies block the calling thread, so a second thread takes the copies out (round 6: 2.15e7 -> 4.3e7
     // columns/s on the bench shape, the page-locked rate; pinning the caller's buffers per call instead costs more than it
-    // saves: 49 ms vs 27 ms for 670 MB).  One stream cannot be chunked: one copy in, the kernels, one copy out.
-    if (S > 1 && host_pinned(pcm) && host_pinned(out->db) && host_pinned(out->rgba) && host_pinned(out->index))
-        return batch_pipeline(e, pcm, S, L, n, hop, reassign, out, nullptr);
-    if (S > 1) {
+    // saves: 49 ms vs 27 ms for 670 MB).  With fewer than sixteen streams the units are runs of a stream's columns (pipe_items);
+    // a batch too short for two units (one stream of < 32,768 columns) goes the plain way: one copy in, the kernels, one copy out.
+    if (host_pinned(pcm) && host_pinned(out->db) && host_pinned(out->rgba) && host_pinned(out->index))
+        rc = batch_pipeline(e, pcm, S, L, n, hop, reassign, out, nullptr);
+    else
         rc = batch_pipeline_pageable(e, pcm, S, L, n, hop, reassign, out);
-        if (rc != kNoThread) return rc;
-    }
+    if (rc != kNoThread && rc != kNoPipeline) return rc;
     const int64_t C = emspec_num_columns(L, n, hop);
     const size_t col_cells = (size_t)C * e->cfg.rows;
     const size_t in_s = (size_t)L * sizeof(float);

@@ -287,8 +287,11 @@ int32_t emspec_live_streams(const emspec_engine* e);
  * Ordinary (pageable) buffers run the same pipeline: the runtime's copies block the calling thread, so the library starts a
  * second host thread for the copies out (and three that touch the destination's pages ahead of it - a result array allocated
  * per call has none resident), all joined before the call returns: the page-locked rate when the pages are resident (4.3e7
- * columns/s on the bench shape), a third of it into a fresh array.  One stream (S = 1) cannot be chunked: one copy in, the
- * kernels, one copy out.  Serves: the renderer-side batched computeColumns of the N-API addon (em-spec_amd/js/index.js).
+ * columns/s on the bench shape), a third of it into a fresh array.  With fewer than sixteen streams (one long recording) the
+ * pipeline's units are runs of >= 16,384 columns of a stream, each computed from the frames that reach it - the same columns
+ * (EXACT mode: the same bytes) as in one piece; a batch too short for two units takes one copy in, the kernels, one copy out.
+ * With the display post-process on, units are whole streams.  Serves: the renderer-side batched computeColumns of the N-API
+ * addon (em-spec_amd/js/index.js).
  */
 int emspec_batch(emspec_engine* e, const float* pcm, int32_t S, int64_t L,
                  int32_t n, int32_t hop, int32_t reassign, const emspec_out* out);

@@ -106,6 +106,30 @@ int main(void) {
         CHECK(emspec_parity_dump(x, pcm, 1, L, n, hop, 1, 0, 1, fpw, fc, frw) == EMSPEC_ERR_STATE, "float32 dump accepted by an exact-mode engine");
         free(pw); free(cc); free(rr); free(qq);
     }
+    /* several streams from ordinary malloc'ed memory: the pipelined path (units through three staging sets, the copies out on
+     * the library's second host thread, its page-touching threads ahead of it) - stream s is the signal scaled by (1 - s/8):
+     * stream 0 must give the single-stream call's bits, every stream its own single-stream call's */
+    {
+        const int S5 = 5;
+        float* p5 = (float*)malloc(sizeof(float) * S5 * L);
+        float* d5 = (float*)malloc(sizeof(float) * S5 * frames * R);
+        unsigned char* i5 = (unsigned char*)malloc((size_t)S5 * frames * R);
+        unsigned char* i1 = (unsigned char*)malloc((size_t)frames * R);
+        for (int s5 = 0; s5 < S5; ++s5) for (long i = 0; i < L; ++i) p5[(size_t)s5 * L + i] = pcm[i] * (1.0f - (float)s5 / 8.0f);
+        emspec_out o5 = {d5, NULL, i5};
+        for (int rep = 0; rep < 2; ++rep) {
+            memset(i5, 0xAB, (size_t)S5 * frames * R);
+            CHECK(emspec_batch(x, p5, S5, L, n, hop, 1, &o5) == EMSPEC_OK, emspec_last_error(x));
+            CHECK(memcmp(d5, xdb, sizeof(float) * frames * R) == 0, "multi-stream pageable batch: stream 0 differs from the single-stream bits");
+            for (int s5 = 1; s5 < S5; ++s5) {
+                emspec_out o1 = {xdb2, NULL, i1};
+                CHECK(emspec_batch(x, p5 + (size_t)s5 * L, 1, L, n, hop, 1, &o1) == EMSPEC_OK, emspec_last_error(x));
+                CHECK(memcmp(d5 + (size_t)s5 * frames * R, xdb2, sizeof(float) * frames * R) == 0, "multi-stream pageable batch: a stream's dB differs from its own call");
+                CHECK(memcmp(i5 + (size_t)s5 * frames * R, i1, (size_t)frames * R) == 0, "multi-stream pageable batch: a stream's palette index differs from its own call");
+            }
+        }
+        free(p5); free(d5); free(i5); free(i1);
+    }
     /* the live multi-stream session from plain C: three streams (the signal, half of it, silence) fed hop by hop through
      * emspec_push_samples_multi from PAGE-LOCKED blocks (emspec_host_alloc: the kernel reads and writes them in place), one
      * restarted half way; stream 0 must give the batch call's bits, the silent stream the floor everywhere */
@@ -185,6 +209,6 @@ int main(void) {
     emspec_destroy(x);
     free(xdb); free(xdb2);
     free(pcm); free(db); free(rgba); free(col);
-    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells; live multi-stream session (3 streams, page-locked and pageable blocks, sample- and frame-fed) == batch bits\n", worst, xworst);
+    printf("abi_driver ok: streaming vs batch max |dB| diff %.2e; exact mode: streaming == batch bits, exact vs fast max %.2e dB on strong cells; 5-stream pageable batch == per-stream bits; live multi-stream session (3 streams, page-locked and pageable blocks, sample- and frame-fed) == batch bits\n", worst, xworst);
     return 0;
 }

@@ -75,6 +75,42 @@ def test_pageable_batch_equals_pinned_batch(mode, S):
 
 
 @pytest.mark.parametrize("mode", ["fast", "exact"])
+@pytest.mark.parametrize("S,pinned", [(1, True), (1, False), (3, False)])
+def test_few_long_streams_are_pipelined_by_runs_of_columns(mode, S, pinned):
+    """Fewer streams than the pipeline has stages (BASELINE configs[1] is ONE stream): a stream's columns are cut into runs of
+    >= 16,384, each computed as a batch of its own from the frames that reach it (D halo frames either side, their columns left
+    behind).  33,100 columns: two runs per stream; the seam must not show - EXACT: bytes equal to the device-resident call's on
+    the whole stream (dB bits and palette index); FAST: its +-1 cells."""
+    import torch
+    n, hop = 4096, 256
+    L = n + hop * 33099 + 100
+    one = synth.streams(1, L)[0]
+    pcm = np.stack([one * (1.0 - 0.2 * s) for s in range(S)]).astype(np.float32)
+    Cn = emspec.num_columns(L, n, hop)
+    assert Cn == 33100
+    with emspec.Engine(mode=emspec.MODE_EXACT if mode == "exact" else emspec.MODE_FAST) as e:
+        if pinned:
+            got = _batch_pinned(e, pcm, n, hop)
+        else:
+            got = e.batch(pcm, n, hop, True, want=("db", "index"))
+        x = torch.from_numpy(pcm).cuda()
+        db = torch.empty((S, Cn, e.rows), dtype=torch.float32, device="cuda")
+        ix = torch.empty((S, Cn, e.rows), dtype=torch.uint8, device="cuda")
+        e.batch_device(x, n, hop, True, db=db, index=ix)
+        torch.cuda.synchronize()
+        rdb, rix = db.cpu().numpy(), ix.cpu().numpy()
+    if mode == "exact":
+        assert np.array_equal(got["index"], rix)
+        assert np.array_equal(got["db"].view(np.uint32), rdb.view(np.uint32))
+    else:
+        d = np.abs(got["index"].astype(np.int16) - rix.astype(np.int16))
+        assert d.max() <= 1 and np.mean(d != 0) < 1e-4
+        assert np.max(np.abs(got["db"] - rdb)) < 1e-3
+        seam = Cn // 2
+        assert np.mean(d[:, seam - 20:seam + 20] != 0) < 1e-3      # no more of them around the seam than anywhere
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
 def test_pipelined_batch_equals_device_resident_batch(mode):
     """23 streams from pinned buffers: 12 chunks of two streams through three staging sets (every set is reused three
     times, the last chunk is short).  EXACT mode: bytes equal to the bit model; FAST mode: palette index equal to the
