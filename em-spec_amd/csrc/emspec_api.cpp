@@ -864,12 +864,29 @@ static int pipe_setup(emspec_engine* e) {
 struct PipeItem { int s0, sc; int64_t c0, cn, first_sample, samples, skip, cols; };
 static constexpr int kNoThread = -1000, kNoPipeline = -1001;   // pipeline not taken (not EMSPEC_ERR_* values): no helper thread / one unit only
 
-static std::vector<PipeItem> pipe_items(int S, int64_t L, int64_t C, int n, int hop, int D, size_t per_stream_bytes, bool by_time) {
-    std::vector<PipeItem> items;
-    int target = 16;
+// How many units a batch is cut into.  The host thread spends ~0.2 ms (EXACT: 0.4) submitting a unit - up to four copies, the
+// kernels, six event calls - whatever its size, and behind it runs a three-stage pipeline: with u units a call takes about
+//     max(u x 0.2 ms,  M + (sum - M) / u),   M = the longest of [bytes in / 45 GB/s, kernel time, bytes out / 45 GB/s].
+// Until late round 6 the count was fixed (sixteen, or one per stream below that): 8 streams x 2^18 samples took 1.65 ms - eight
+// units' submissions - for 0.5 ms of copies and kernels.  The kernel rates are the bench line's, rounded; at most sixteen units.
+static int pipe_units(bool exact, int n, int64_t columns, size_t bytes_in, size_t bytes_out) {
+    const double rate = (n <= 1024 ? 3.4e8 : n <= 2048 ? 2.2e8 : n <= 4096 ? 1.15e8 : n <= 8192 ? 5e7 : 2.2e7) / (exact ? (n > 4096 ? 2.8 : 2.1) : 1.0);
+    const double t_in = (double)bytes_in / 45e9, t_out = (double)bytes_out / 45e9, t_k = (double)columns / rate;
+    const double longest = std::max(t_in, std::max(t_k, t_out)), sum = t_in + t_k + t_out, per_unit = exact ? 0.4e-3 : 0.2e-3;
+    int best = 1;
+    double best_t = sum + per_unit;
+    for (int u = 2; u <= 16; ++u) {
+        const double t = std::max(u * per_unit, longest + (sum - longest) / u);
+        if (t < best_t * 0.97) { best = u; best_t = t; }   // (3 %: not one unit more for nothing)
+    }
 #ifdef EMSPEC_DIAG
-    if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) target = v; }   // A/B aid
+    if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) best = v; }   // A/B aid
 #endif
+    return best;
+}
+
+static std::vector<PipeItem> pipe_items(int S, int64_t L, int64_t C, int n, int hop, int D, size_t per_stream_bytes, bool by_time, int target) {
+    std::vector<PipeItem> items;
     // runs of columns: when there are fewer than `target` streams; at least 16,384 columns per run - a unit costs ~0.2 ms of
     // launches and cross-stream event waits (EXACT: 0.4) whatever its size, and 16 MB each way over PCIe take 0.35 ms (measured
     // with 2,048-column runs: one stream of 2^22 samples 1.49 ms instead of 0.84 in one piece)
@@ -890,8 +907,8 @@ static std::vector<PipeItem> pipe_items(int S, int64_t L, int64_t C, int n, int 
             }
         return items;
     }
-    // chunks of streams: about `target` per batch (pipeline fill and drain stay small beside the steady state), bounded by
-    // 1 GiB of staging per set; a chunk of a few streams still fills the chip (segments are cut per launch)
+    // chunks of streams: about `target` per batch (pipe_units), bounded by 1 GiB of staging per set; a chunk of a few streams
+    // still fills the chip (segments are cut per launch)
     int chunk = (S + target - 1) / target;
     const int fit = (int)(((size_t)1 << 30) / per_stream_bytes);
     chunk = chunk > fit ? fit : chunk;
@@ -914,7 +931,9 @@ static int batch_pipeline(emspec_engine* e, const float* pcm, int32_t S, int64_t
     const size_t per_stream = al(in_s) + al(want_db ? col_cells * 4 : 0) + al(want_rgba ? col_cells * 4 : 0) + al(want_idx ? col_cells : 0) + al(wire_s);
     // (an image is one stream's whole run of columns, and the display post-process walks a stream in time order: whole streams there)
     const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
-    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !pk && !post);
+    const int units = pipe_units(e->exact(), n, (int64_t)S * C, (size_t)S * in_s,
+                                 pk ? (size_t)S * col_cells / 5 : (size_t)S * col_cells * ((want_db ? 4 : 0) + (want_rgba ? 4 : 0) + (out && out->index ? 1 : 0)));
+    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !pk && !post, units);
     const int nchunks = (int)items.size();
     if (nchunks < 2 && !pk) return kNoPipeline;   // one unit: nothing to overlap (the caller's plain path)
     // the staging set: every array at the size its largest unit needs
@@ -1047,7 +1066,9 @@ static int batch_pipeline_pageable(emspec_engine* e, const float* pcm, int32_t S
     const bool want_db = out->db != nullptr, want_rgba = out->rgba != nullptr, want_idx = out->index != nullptr;
     const size_t per_stream = al(in_s) + al(want_db ? col_cells * 4 : 0) + al(want_rgba ? col_cells * 4 : 0) + al(want_idx ? col_cells : 0);
     const bool post = e->smoothing > 0.0f || e->agc > 0.0f;
-    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !post);
+    const int units = pipe_units(e->exact(), n, (int64_t)S * C, (size_t)S * in_s,
+                                 (size_t)S * col_cells * ((want_db ? 4 : 0) + (want_rgba ? 4 : 0) + (want_idx ? 1 : 0)));
+    const std::vector<PipeItem> items = pipe_items(S, L, C, n, hop, latency(n, hop, reassign), per_stream, !post, units);
     const int nchunks = (int)items.size();
     if (nchunks < 2) return kNoPipeline;   // one unit: nothing to overlap
     size_t cap_in = 0, cap_cells = 0;

@@ -49,6 +49,7 @@ timeout -k 10 300 python tools/host_rates.py > gpurun_out/${tag}_host_api_rate.t
 timeout -k 10 300 python tools/host_pipeline_rates.py > gpurun_out/${tag}_host_pipeline_rate.txt 2>&1 || true
 (timeout -k 10 200 python tools/host_pageable_rate.py; timeout -k 10 200 python tools/host_pageable_rate.py --exact) > gpurun_out/${tag}_host_pageable_rate.txt 2>&1 || true
 (timeout -k 10 200 python tools/host_few_streams_rate.py; timeout -k 10 200 python tools/host_few_streams_rate.py --exact) > gpurun_out/${tag}_host_few_streams_rate.txt 2>&1 || true
+(timeout -k 10 200 python tools/host_small_batch_rate.py; timeout -k 10 200 python tools/host_small_batch_rate.py --exact) > gpurun_out/${tag}_host_small_batch_rate.txt 2>&1 || true
 # round 6: the live multi-stream entries (per-call host time of every variant; the frame kernel's phases), EXACT at the small sizes
 timeout -k 10 300 python tools/live_rate.py 64 400 > gpurun_out/${tag}_live_rate.txt 2>&1 || true
 timeout -k 10 200 python tools/live_phases.py 64 200 > gpurun_out/${tag}_live_phases.txt 2>&1 || true
