@@ -877,7 +877,7 @@ static int pipe_units(bool exact, int n, int64_t columns, size_t bytes_in, size_
     double best_t = sum + per_unit;
     for (int u = 2; u <= 16; ++u) {
         const double t = std::max(u * per_unit, longest + (sum - longest) / u);
-        if (t < best_t * 0.97) { best = u; best_t = t; }   // (3 %: not one unit more for nothing)
+        if (t < best_t * 0.995) { best = u; best_t = t; }   // (not one unit more for nothing)
     }
 #ifdef EMSPEC_DIAG
     if (const char* ev = getenv("EMSPEC_PIPE_CHUNKS")) { const int v = atoi(ev); if (v >= 1) best = v; }   // A/B aid
