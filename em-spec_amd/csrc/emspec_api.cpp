@@ -864,11 +864,14 @@ static int pipe_setup(emspec_engine* e) {
 struct PipeItem { int s0, sc; int64_t c0, cn, first_sample, samples, skip, cols; };
 static constexpr int kNoThread = -1000, kNoPipeline = -1001;   // pipeline not taken (not EMSPEC_ERR_* values): no helper thread / one unit only
 
-// How many units a batch is cut into.  The host thread spends ~0.2 ms (EXACT: 0.4) submitting a unit - up to four copies, the
-// kernels, six event calls - whatever its size, and behind it runs a three-stage pipeline: with u units a call takes about
+// How many units a batch is cut into.  A unit costs ~0.2 ms (EXACT: 0.4) on the compute stream whatever its size: a launch of
+// the fused kernel takes 0.11-0.18 ms however few columns it has - a workgroup WALKS its segment, 2 D halo frames and the ring's
+// start-up before the first column leaves (emspec_batch_device on 49 columns: 113 us on the GPU, 5 us to enqueue) - the units'
+// kernels run one after the other, and each unit adds ~40 us of event waits and copy start-up.  Behind that, three stages
+// overlap: with u units a call takes about
 //     max(u x 0.2 ms,  M + (sum - M) / u),   M = the longest of [bytes in / 45 GB/s, kernel time, bytes out / 45 GB/s].
 // Until late round 6 the count was fixed (sixteen, or one per stream below that): 8 streams x 2^18 samples took 1.65 ms - eight
-// units' submissions - for 0.5 ms of copies and kernels.  The kernel rates are the bench line's, rounded; at most sixteen units.
+// units - for 0.5 ms of copies and kernels.  The kernel rates are the bench line's, rounded; at most sixteen units.
 static int pipe_units(bool exact, int n, int64_t columns, size_t bytes_in, size_t bytes_out) {
     const double rate = (n <= 1024 ? 3.4e8 : n <= 2048 ? 2.2e8 : n <= 4096 ? 1.15e8 : n <= 8192 ? 5e7 : 2.2e7) / (exact ? (n > 4096 ? 2.8 : 2.1) : 1.0);
     const double t_in = (double)bytes_in / 45e9, t_out = (double)bytes_out / 45e9, t_k = (double)columns / rate;
@@ -887,9 +890,9 @@ static int pipe_units(bool exact, int n, int64_t columns, size_t bytes_in, size_
 
 static std::vector<PipeItem> pipe_items(int S, int64_t L, int64_t C, int n, int hop, int D, size_t per_stream_bytes, bool by_time, int target) {
     std::vector<PipeItem> items;
-    // runs of columns: when there are fewer than `target` streams; at least 16,384 columns per run - a unit costs ~0.2 ms of
-    // launches and cross-stream event waits (EXACT: 0.4) whatever its size, and 16 MB each way over PCIe take 0.35 ms (measured
-    // with 2,048-column runs: one stream of 2^22 samples 1.49 ms instead of 0.84 in one piece)
+    // runs of columns: when there are fewer than `target` streams; at least 16,384 columns per run - a unit costs ~0.2 ms
+    // (pipe_units) whatever its size, and 16 MB each way over PCIe take 0.35 ms (measured with 2,048-column runs: one stream
+    // of 2^22 samples 1.49 ms instead of 0.84 in one piece)
     const int64_t pieces = by_time && S < target ? std::min<int64_t>((target + S - 1) / S, C / 16384) : 1;
     if (pieces > 1) {
         for (int s = 0; s < S; ++s)
